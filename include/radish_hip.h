@@ -1,0 +1,158 @@
+/* include/radish_hip.h — C ABI of libradish_hip.so, the MI355X (gfx950) implementation of Radish's per-pixel
+ * path-tracing inner loop.
+ *
+ * The reference has no FFI layer: its render API is a set of C++ free functions that read process globals
+ * (SURVEY.md §8b).  Each entry point below names the reference function whose body it replaces; the
+ * source-compatible C++ shim with the reference's exact signatures is radish_pt_amd/csrc/radish_shim.hpp, and
+ * INTEGRATION.md shows the binding a Radish maintainer would add.
+ *
+ * Conventions: every function returns 0 on success or a negative RDH_ERR_* / positive hipError_t code, and
+ * rdh_last_error() gives the message (the reference prints and exit()s: src/cudaUtil.h:16-34 — the shim
+ * reproduces that).  All `d_*` pointers are DEVICE pointers owned by the caller; scene arrays passed to
+ * rdh_scene_upload are HOST pointers in the reference's DevScene layout.  A context is bound to one device and
+ * one stream and is not thread-safe; calls are asynchronous on that stream unless stated otherwise.
+ */
+#ifndef RADISH_HIP_H
+#define RADISH_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDH_OK 0
+#define RDH_ERR_ARGS (-1)        /* null / inconsistent arguments                         */
+#define RDH_ERR_NO_SCENE (-2)    /* call needs rdh_scene_upload + rdh_set_camera first    */
+#define RDH_ERR_UNSUPPORTED (-3) /* textures / env map: not built yet                     */
+#define RDH_ERR_NO_DEVICE (-4)   /* no usable HIP device — there is NO CPU fallback       */
+#define RDH_ERR_STATE (-5)       /* e.g. rdh_restir_direct before rdh_restir_init         */
+
+typedef struct rdh_ctx rdh_ctx;
+
+/* Host arrays in the reference's DevScene layout (src/scene.h:494-517).
+ * Replaces the argument of DevScene::create(const Scene&) (src/scene.cpp:461-551). */
+typedef struct rdh_scene_desc {
+    const float *vertices;       /* glm::vec3[3*numPrims], world-space triangle soup (src/scene.cpp:198-222) */
+    const float *normals;        /* glm::vec3[3*numPrims]                                                     */
+    const float *texcoords;      /* glm::vec2[3*numPrims]                                                     */
+    const float *boundingBoxes;  /* AABB[bvhSize] = {pMin, pMax} (src/bvh.h:157-158)                           */
+    const int32_t *bvhNodes[6];  /* MTBVHNode[bvhSize] = {primitiveId, boundingBoxId, nextNodeIfMiss} (:167-169) */
+    int32_t bvhSize;             /* 2*numPrims-1                                                               */
+    int32_t numPrims;
+    const int32_t *materialIds;  /* int[numPrims]                                                              */
+    const void *materials;       /* Material[numMaterials], 44 B each (src/material.h:276-286)                 */
+    int32_t numMaterials;
+    int32_t numLights;
+    const int32_t *lightPrimIds;      /* int[numLights]                                                        */
+    const float *lightUnitRadiance;   /* glm::vec3[numLights]                                                  */
+    float sumLightPowerInv;           /* 1 / lightSampler.sum (src/scene.cpp:527)                              */
+    int32_t lightSamplerLength;       /* DevDiscreteSampler1D::length (== numLights without an env map)        */
+    const void *lightSampler;         /* BinomialDistrib<float>[length] = {float prob; int failId}             */
+    const uint32_t *sampleSequence;   /* uint32[10000][200] Sobol table (src/scene.cpp:543-548)                */
+} rdh_scene_desc;
+
+/* Byte-for-byte the reference's GBuffer (src/gBuffer.h:42-57, 272 B) with DENOISER_ENCODE_NORMAL=false,
+ * DENOISER_ENCODE_POSITION=true: device pointers owned by the caller (GBuffer::create, src/denoiser.cu:329-359). */
+typedef struct rdh_gbuffer {
+    float *albedo;     /* glm::vec3[w*h]                                         */
+    float *normal[2];  /* glm::vec3[w*h] x2 (double-buffered by frameIdx)        */
+    int32_t *motion;   /* int[w*h]                                               */
+    float *depth[2];   /* float[w*h] x2                                          */
+    int32_t *primId[2];/* int[w*h] x2 — holds the MATERIAL id, -2 light, -1 miss */
+    int32_t frameIdx;
+    uint8_t lastCam[196];
+    int32_t width, height;
+} rdh_gbuffer;
+
+typedef struct rdh_hit { int32_t primId; float u, v, t; } rdh_hit;
+
+/* Exact work counters of the launches since the last reset (device atomics, one add per wave). */
+typedef struct rdh_counters {
+    uint64_t closestRays; /* DevScene::intersect calls       */
+    uint64_t anyRays;     /* DevScene::testOcclusion calls   */
+    uint64_t nodeVisits;  /* AABB tests                      */
+    uint64_t triTests;    /* triangle tests                  */
+    uint64_t closestHits;
+} rdh_counters;
+
+/* rdh_path_trace flags */
+#define RDH_PT_MEGAKERNEL 0u   /* one lane per pixel, whole path in one launch (the reference's structure)  */
+#define RDH_PT_WAVEFRONT 1u    /* raygen / extend / shade / connect queues with wave64 ballot compaction    */
+#define RDH_PT_SORT_MATERIAL 2u/* wavefront only: bin hits by BSDF type before shading                      */
+#define RDH_PT_COUNT 4u        /* maintain rdh_counters (adds atomics; leave off when timing)               */
+
+/* ReSTIR reuse mask = ReservoirReuse (src/common.h:41-48) */
+#define RDH_REUSE_TEMPORAL 1
+#define RDH_REUSE_SPATIAL 2
+
+typedef struct rdh_restir_params {
+    int32_t reuseMask;    /* Settings::reservoirReuse                                              */
+    int32_t risCount;     /* RESERVOIR_SIZE = 32 (src/restir.h:9)                                   */
+    int32_t numSpatial;   /* 5 in the reference (src/restir.cu:87); BASELINE config 4 also asks for 4 */
+    int32_t temporalClamp;/* 20 (src/restir.cu:168)                                                 */
+    int32_t faithfulRIS;  /* 1 = Reservoir::update's truthiness test (src/restir.h:21), 0 = corrected */
+} rdh_restir_params;
+
+/* ---- lifetime ---------------------------------------------------------------------------------------- */
+int rdh_create(rdh_ctx **out, int device);
+void rdh_destroy(rdh_ctx *ctx);
+const char *rdh_last_error(const rdh_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
+int rdh_set_stream(rdh_ctx *ctx, void *hipStream);
+int rdh_synchronize(rdh_ctx *ctx);
+
+/* ---- scene / camera -------------------------------------------------------------------------------- */
+/* Replaces DevScene::create (src/scene.cpp:461-551): uploads and re-lays-out the scene (32-byte threaded nodes,
+ * 48-byte triangle records, packed light records).  Blocking. */
+int rdh_scene_upload(rdh_ctx *ctx, const rdh_scene_desc *desc);
+/* Replaces DevScene::destroy (src/scene.cpp:553-574). */
+int rdh_scene_free(rdh_ctx *ctx);
+/* The `Camera cam` kernel argument of every reference kernel (State::scene->camera, src/pathtrace.cu:356). */
+int rdh_set_camera(rdh_ctx *ctx, const void *camera196);
+
+/* ---- multi-GPU tile partition (no reference counterpart) --------------------------------- */
+/* The frame is cut into tileSize x tileSize pixel tiles, tile t belongs to rank t % world.  With world > 1 the
+ * image arguments of the render calls are PACKED per-rank buffers: float[tilesPerRank][tileSize*tileSize][3],
+ * tilesPerRank = rdh_tiles_per_rank(); gather them over RCCL and call rdh_untile.  world == 1 renders straight
+ * into frame layout (y*W+x), which is the reference's. */
+int rdh_set_partition(rdh_ctx *ctx, int rank, int world, int tileSize);
+int rdh_tiles_per_rank(const rdh_ctx *ctx);
+/* d_gathered: float[world][tilesPerRank][tileSize^2][3] (all-gather output) -> d_frame: float[H*W][3]. */
+int rdh_untile(rdh_ctx *ctx, const float *d_gathered, float *d_frame);
+
+/* ---- the hot path ---------------------------------------------------------------------------------- */
+/* Replaces pathTrace(glm::vec3*, glm::vec3*, int) (src/pathtrace.cu:351-385) minus the State::looper increment
+ * (the caller / shim owns the globals).  looper = State::looper, maxDepth = Settings::traceDepth. */
+int rdh_path_trace(rdh_ctx *ctx, float *d_directIllum, float *d_indirectIllum, int iter, int looper, int maxDepth,
+                   uint32_t flags);
+/* Replaces pathTraceDirect(glm::vec3*, int) (src/pathtrace.cu:387-407). */
+int rdh_path_trace_direct(rdh_ctx *ctx, float *d_directIllum, int iter, int looper, uint32_t flags);
+/* Replaces GBuffer::render(DevScene*, const Camera&) (src/gBuffer.cu:83-103). */
+int rdh_gbuffer_render(rdh_ctx *ctx, const rdh_gbuffer *gb, uint32_t flags);
+/* Replaces ReSTIRInit / ReSTIRFree (src/restir.cu:235-251): three DirectReservoir[w*h] buffers, zeroed. */
+int rdh_restir_init(rdh_ctx *ctx);
+int rdh_restir_free(rdh_ctx *ctx);
+/* Replaces ReSTIRDirect(glm::vec3*, int, const GBuffer&) (src/restir.cu:205-233) incl. the reservoir swap and
+ * the first-frame flag; two launches instead of one so that spatial reuse is race-free. */
+int rdh_restir_direct(rdh_ctx *ctx, float *d_directIllum, int iter, int looper, const rdh_gbuffer *gb,
+                      const rdh_restir_params *params, uint32_t flags);
+/* Test access to the reservoir buffers (36-byte DirectReservoir[w*h]): which = 0 current out, 1 last, 2 temp. */
+int rdh_restir_read(rdh_ctx *ctx, int which, void *hostOut);
+
+/* ---- traversal entry points (tests / roofline bench) ------------------------------------------------ */
+/* d_rays: {origin.xyz, direction.xyz}[n].  DevScene::intersect (src/scene.h:262-301) per ray. */
+int rdh_trace_closest(rdh_ctx *ctx, const float *d_rays, int64_t n, rdh_hit *d_hits, uint32_t flags);
+/* d_segments: {x.xyz, y.xyz}[n] -> d_occluded[n] in {0,1}.  DevScene::testOcclusion (src/scene.h:303-334). */
+int rdh_trace_occluded(rdh_ctx *ctx, const float *d_segments, int64_t n, int32_t *d_occluded, uint32_t flags);
+
+int rdh_counters_reset(rdh_ctx *ctx);
+int rdh_counters_read(rdh_ctx *ctx, rdh_counters *out); /* blocking */
+
+/* Time of the most recent render call's kernels, measured with hipEvents on the context's stream (blocking);
+ * the reference prints this figure from pathTrace (src/pathtrace.cu:364-374). */
+int rdh_last_kernel_ms(rdh_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

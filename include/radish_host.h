@@ -1,0 +1,43 @@
+/* include/radish_host.h — host-side scene preparation (CPU only, no HIP).
+ *
+ * These entry points produce the arrays of the reference's DevScene layout from a world-space triangle
+ * soup.  They are the "step before the path" (SURVEY.md §8f N2): in a Radish build they replace the bodies
+ * of BVHBuilder::build, DiscreteSampler1D's constructor and the light-list loop of Scene::buildDevData,
+ * whose outputs DevScene::create uploads (src/scene.cpp:461-551).  libradish_host.so, built with g++.
+ */
+#ifndef RADISH_HOST_H
+#define RADISH_HOST_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Replaces BVHBuilder::build + buildMTBVH (src/bvh.cpp:12-134,136-183).
+ * vertices: float[numPrims*9] triangle soup.  boxesOut: float[(2*numPrims-1)*6] AABBs in depth-first order.
+ * nodesOut[i]: int32[(2*numPrims-1)*3] = {primitiveId, boundingBoxId, nextNodeIfMiss}, i = 0..5 (the six
+ * direction-ordered threaded arrays).  Returns BVHSize = 2*numPrims-1, or a negative error code. */
+int32_t rdh_build_bvh(const float *vertices, int32_t numPrims, float *boxesOut, int32_t *const nodesOut[6]);
+
+/* Replaces DiscreteSampler1D<float>::DiscreteSampler1D (src/sampler.h:81-125).
+ * tableOut: {float prob; int32 failId}[n].  *sumOut receives the float sum of `values`. Returns 0 / <0. */
+int32_t rdh_build_alias_table(const float *values, int32_t n, void *tableOut, float *sumOut);
+
+/* Replaces the emissive-triangle loop of Scene::buildDevData (src/scene.cpp:192-223).
+ * materials: 44-byte Material[numMaterials].  Outputs sized for numPrims entries; returns the light count.
+ * lightPowerOut[i] = luminance(baseColor) * 2 * pi * area. */
+int32_t rdh_build_light_list(const float *vertices, const int32_t *materialIds, int32_t numPrims,
+                             const void *materials, int32_t numMaterials, int32_t *lightPrimIdsOut,
+                             float *lightUnitRadianceOut, float *lightPowerOut);
+
+/* Replaces Camera::update (src/sceneStructs.h:93-107) plus the fov bookkeeping of Scene::loadCamera
+ * (src/scene.cpp:378-383).  camera196 in/out: resolution, position, rotation, fov.y (degrees, "FovY"),
+ * lensRadius, focalDist must be set; view/up/right/rotationMatInv/fov.x/tanFovY/viewProjection are written. */
+void rdh_camera_update(void *camera196);
+
+#define RDH_HOST_ERR_ARGS (-1)
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+/* oracle/oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * C ABI of the single-threaded CPU restatement of Radish's per-pixel path-tracing inner loop
+ * (/root/reference/src/pathtrace.cu, restir.cu and the device code they inline).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so; the product
+ * (radish_pt_amd/, libradish_hip.so) never includes, links or calls anything in this directory.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors, scenes or Sobol table, cannot be
+ * compiled in this image (no nvcc/glm/stb/GLFW/xmake; MSVC-only headers) and depends on glm + CUDA
+ * libdevice arithmetic that is not under /root/reference.  This oracle is therefore
+ * pinned only by hand-computed known-answer tests (tests/test_oracle_kat.py) and by internal
+ * cross-checks (BVH walk vs brute force, white-furnace, alias-table sums).
+ */
+#ifndef RADISH_ORACLE_H
+#define RADISH_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Host arrays in the reference's DevScene layout (src/scene.h:494-517). */
+typedef struct orc_scene_desc {
+    const float *vertices;      /* vec3[3*numPrims]  (triangle soup)            */
+    const float *normals;       /* vec3[3*numPrims]                             */
+    const float *texcoords;     /* vec2[3*numPrims]                             */
+    const float *boundingBoxes; /* AABB[bvhSize] = {pMin.xyz, pMax.xyz}         */
+    const int32_t *bvhNodes[6]; /* MTBVHNode[bvhSize] = {primId, boxId, next}   */
+    int32_t bvhSize;            /* 2*numPrims-1                                 */
+    int32_t numPrims;
+    const int32_t *materialIds; /* int[numPrims]                                */
+    const void *materials;      /* Material[numMaterials], 44 B each            */
+    int32_t numMaterials;
+    int32_t numLights;          /* entries in lightPrimIds / lightUnitRadiance  */
+    const int32_t *lightPrimIds;
+    const float *lightUnitRadiance; /* vec3[numLights]                          */
+    float sumLightPowerInv;
+    int32_t lightSamplerLength;     /* alias table length (== numLights, no env map) */
+    const void *lightSampler;       /* BinomialDistrib<float>[len] = {float prob; int failId} */
+    const uint32_t *sobol;          /* uint32[10000][200]                        */
+} orc_scene_desc;
+
+/* G-buffer in the reference's field order (src/gBuffer.h:42-57), host pointers. */
+typedef struct orc_gbuffer {
+    float *albedo;     /* vec3[w*h]  */
+    float *normal[2];  /* vec3[w*h]  */
+    int32_t *motion;   /* int[w*h]   */
+    float *depth[2];   /* float[w*h] */
+    int32_t *primId[2];/* int[w*h] — holds the MATERIAL id, -2 light, -1 miss (gBuffer.cu:32-47) */
+    int32_t frameIdx;
+    int32_t width, height;
+} orc_gbuffer;
+
+typedef struct orc_stats {
+    uint64_t closestRays;  /* calls to DevScene::intersect      */
+    uint64_t anyRays;      /* calls to DevScene::testOcclusion  */
+    uint64_t nodeVisits;   /* AABB tests, both walk kinds        */
+    uint64_t triTests;     /* Möller–Trumbore tests              */
+    uint64_t closestHits;  /* intersect calls that found a hit   */
+} orc_stats;
+
+typedef struct orc_hit { int32_t primId; float u, v, t; } orc_hit;
+
+typedef struct orc_scene orc_scene;
+
+/* The descriptor's arrays are borrowed, not copied: keep them alive while the handle is used. */
+orc_scene *orc_scene_create(const orc_scene_desc *desc);
+void orc_scene_destroy(orc_scene *s);
+void orc_stats_reset(orc_scene *s);
+void orc_stats_get(const orc_scene *s, orc_stats *out);
+
+/* rays: {origin.xyz, direction.xyz} x n.  Restates DevScene::intersect (scene.h:262-301). */
+void orc_trace_closest(orc_scene *s, const float *rays, int64_t n, orc_hit *hits);
+/* Same result contract, brute force over all triangles (scene.h:209-232 naiveIntersect). */
+void orc_trace_closest_naive(orc_scene *s, const float *rays, int64_t n, orc_hit *hits);
+/* segments: {x.xyz, y.xyz} x n -> 1 if occluded.  Restates DevScene::testOcclusion (scene.h:303-334). */
+void orc_trace_occluded(orc_scene *s, const float *segments, int64_t n, int32_t *occluded);
+
+/* camera196: the reference's 196-byte Camera (sceneStructs.h:118-130).
+ * Pixels processed: index = pixBegin, pixBegin+pixStride, ... < pixEnd (row-major y*W+x). */
+void orc_path_trace(orc_scene *s, const void *camera196, float *directIllum, float *indirectIllum,
+                    int iter, int looper, int maxDepth, int64_t pixBegin, int64_t pixEnd, int64_t pixStride);
+void orc_path_trace_direct(orc_scene *s, const void *camera196, float *directIllum, int iter, int looper,
+                           int64_t pixBegin, int64_t pixEnd, int64_t pixStride);
+void orc_gbuffer_render(orc_scene *s, const void *camera196, const void *lastCamera196, orc_gbuffer *gb);
+
+/* Two-pass ReSTIR DI (restir.cu:97-203 with the race of SURVEY F6 removed by a pass boundary).
+ * reservoirs: DirectReservoir[w*h] of 36 B each.  reuseMask: bit0 temporal, bit1 spatial.
+ * faithfulRIS != 0 reproduces Reservoir::update's truthiness test (restir.h:21). */
+void orc_restir_direct(orc_scene *s, const void *camera196, float *directIllum, int iter, int looper,
+                       void *reservoirOut, const void *reservoirIn, void *reservoirTemp,
+                       const orc_gbuffer *gb, int firstFrame, int reuseMask, int faithfulRIS,
+                       int numSpatial, int risCount);
+
+/* Known-answer-test hooks for single device functions. */
+uint32_t orc_utilhash(uint32_t a);
+int orc_aabb_intersect(const float *box6, const float *ray6, float *tMin);
+int orc_intersect_triangle(const float *ray6, const float *v9, float *bary2, float *dist);
+void orc_sincos(float x, float *s, float *c);
+/* BSDF hooks: material44 = 44-byte Material; which: 0 BSDF (out[0..2]), 1 pdf (out[0]),
+ * 2 sample (r3 -> out = dir.xyz, bsdf.xyz, pdf, type as float bits). */
+void orc_material_eval(const void *material44, int which, const float *n3, const float *wo3, const float *wi_or_r3,
+                       float *out8);
+void orc_camera_sample(const void *camera196, int x, int y, const float *r4, float *ray6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

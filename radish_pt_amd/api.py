@@ -1,0 +1,406 @@
+"""Host-side mirror of the reference's render API over libradish_hip.so (include/radish_hip.h).
+
+Same names, argument meaning and side effects as the reference's C++ free functions and globals
+(`/root/reference/src/pathtrace.h:18-23`, `restir.h:103-106`, `gBuffer.h:24-27`, `common.h:50-72`):
+
+    Settings.traceDepth, Settings.reservoirReuse, State.looper, State.scene
+    pathTraceInit() / pathTraceFree()
+    pathTrace(directIllum, indirectIllum, iter)          # advances State.looper mod 10000
+    pathTraceDirect(directIllum, iter)
+    ReSTIRInit() / ReSTIRFree() / ReSTIRDirect(directIllum, iter, gBuffer)
+    GBuffer.create(w, h) / destroy() / render(devScene, cam) / update(cam)
+    DevScene.create(scene) / destroy()
+
+Images are CUDA (HIP) float32 torch tensors of shape [H*W, 3] — the reference's `glm::vec3*` device buffers.  PyTorch
+is plumbing here (device memory, streams, torch.distributed); every computation happens in the HIP library.  There is
+no CPU path: importing works without a GPU, calling anything raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import layouts as L
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libradish_hip.so")
+
+RDH_PT_MEGAKERNEL, RDH_PT_WAVEFRONT, RDH_PT_SORT_MATERIAL, RDH_PT_COUNT = 0, 1, 2, 4
+SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12
+
+# Every symbol include/radish_hip.h declares (tests check that the library exports all of them).
+EXPORTS = [
+    "rdh_create", "rdh_destroy", "rdh_last_error", "rdh_set_stream", "rdh_synchronize", "rdh_scene_upload",
+    "rdh_scene_free", "rdh_set_camera", "rdh_set_partition", "rdh_tiles_per_rank", "rdh_untile", "rdh_path_trace",
+    "rdh_path_trace_direct", "rdh_gbuffer_render", "rdh_restir_init", "rdh_restir_free", "rdh_restir_direct",
+    "rdh_restir_read", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
+    "rdh_last_kernel_ms",
+]
+
+
+class SceneDescC(C.Structure):
+    _fields_ = [
+        ("vertices", C.c_void_p), ("normals", C.c_void_p), ("texcoords", C.c_void_p), ("boundingBoxes", C.c_void_p),
+        ("bvhNodes", C.c_void_p * 6), ("bvhSize", C.c_int32), ("numPrims", C.c_int32),
+        ("materialIds", C.c_void_p), ("materials", C.c_void_p), ("numMaterials", C.c_int32),
+        ("numLights", C.c_int32), ("lightPrimIds", C.c_void_p), ("lightUnitRadiance", C.c_void_p),
+        ("sumLightPowerInv", C.c_float), ("lightSamplerLength", C.c_int32), ("lightSampler", C.c_void_p),
+        ("sampleSequence", C.c_void_p),
+    ]
+
+
+class GBufferC(C.Structure):  # == the reference's GBuffer, 272 bytes
+    _fields_ = [
+        ("albedo", C.c_void_p), ("normal", C.c_void_p * 2), ("motion", C.c_void_p), ("depth", C.c_void_p * 2),
+        ("primId", C.c_void_p * 2), ("frameIdx", C.c_int32), ("lastCam", C.c_uint8 * 196), ("width", C.c_int32),
+        ("height", C.c_int32),
+    ]
+
+
+assert C.sizeof(GBufferC) == 272
+
+
+class CountersC(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("closestRays", "anyRays", "nodeVisits", "triTests", "closestHits")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class RestirParamsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("reuseMask", "risCount", "numSpatial", "temporalClamp", "faithfulRIS")]
+
+
+_lib = None
+
+
+def lib():
+    """Load libradish_hip.so; raises if it has not been built — there is no fallback implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(
+                f"{HIP_LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "radish_pt_amd has no CPU or PyTorch fallback for the render path."
+            )
+        l = C.CDLL(HIP_LIB_PATH)
+        vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+        sig = {
+            "rdh_create": ([C.POINTER(vp), i32], i32),
+            "rdh_destroy": ([vp], None),
+            "rdh_last_error": ([vp], C.c_char_p),
+            "rdh_set_stream": ([vp, vp], i32),
+            "rdh_synchronize": ([vp], i32),
+            "rdh_scene_upload": ([vp, C.POINTER(SceneDescC)], i32),
+            "rdh_scene_free": ([vp], i32),
+            "rdh_set_camera": ([vp, vp], i32),
+            "rdh_set_partition": ([vp, i32, i32, i32], i32),
+            "rdh_tiles_per_rank": ([vp], i32),
+            "rdh_untile": ([vp, vp, vp], i32),
+            "rdh_path_trace": ([vp, vp, vp, i32, i32, i32, u32], i32),
+            "rdh_path_trace_direct": ([vp, vp, i32, i32, u32], i32),
+            "rdh_gbuffer_render": ([vp, C.POINTER(GBufferC), u32], i32),
+            "rdh_restir_init": ([vp], i32),
+            "rdh_restir_free": ([vp], i32),
+            "rdh_restir_direct": ([vp, vp, i32, i32, C.POINTER(GBufferC), C.POINTER(RestirParamsC), u32], i32),
+            "rdh_restir_read": ([vp, i32, vp], i32),
+            "rdh_trace_closest": ([vp, vp, i64, vp, u32], i32),
+            "rdh_trace_occluded": ([vp, vp, i64, vp, u32], i32),
+            "rdh_counters_reset": ([vp], i32),
+            "rdh_counters_read": ([vp, C.POINTER(CountersC)], i32),
+            "rdh_last_kernel_ms": ([vp, C.POINTER(C.c_float)], i32),
+        }
+        for name, (args, res) in sig.items():
+            fn = getattr(l, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = l
+    return _lib
+
+
+class RadishError(RuntimeError):
+    pass
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class Context:
+    """One rdh_ctx (one device, one stream)."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        torch = _torch()  # imported first so that the HIP runtime torch ships is the one the library binds to
+        if not torch.cuda.is_available():
+            raise RadishError("radish_pt_amd needs a HIP device; there is no CPU fallback")
+        h = C.c_void_p()
+        rc = lib().rdh_create(C.byref(h), device)
+        if rc != 0:
+            raise RadishError(f"rdh_create failed with code {rc} (no usable HIP device?)")
+        self.h = h
+        self.device = device
+        if use_torch_stream:
+            self.check(lib().rdh_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+
+    def check(self, rc):
+        if rc != 0:
+            msg = lib().rdh_last_error(self.h)
+            raise RadishError(f"libradish_hip error {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rdh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scene / camera ----
+    def upload_scene(self, sd):
+        d = SceneDescC()
+        d.vertices, d.normals, d.texcoords = sd.vertices.ctypes.data, sd.normals.ctypes.data, sd.texcoords.ctypes.data
+        d.boundingBoxes = sd.boxes.ctypes.data
+        d.bvhNodes = (C.c_void_p * 6)(*[a.ctypes.data for a in sd.nodes])
+        d.bvhSize, d.numPrims = sd.bvh_size, sd.num_prims
+        d.materialIds, d.materials, d.numMaterials = sd.material_ids.ctypes.data, sd.materials.ctypes.data, len(sd.materials)
+        d.numLights = sd.num_lights
+        d.lightPrimIds = sd.light_prim_ids.ctypes.data
+        d.lightUnitRadiance = sd.light_unit_radiance.ctypes.data
+        d.sumLightPowerInv = float(sd.sum_light_power_inv)
+        d.lightSamplerLength = len(sd.light_sampler)
+        d.lightSampler = sd.light_sampler.ctypes.data
+        d.sampleSequence = sd.sobol.ctypes.data
+        self.check(lib().rdh_scene_upload(self.h, C.byref(d)))
+
+    def set_camera(self, cam):
+        buf = np.frombuffer(np.asarray(cam, dtype=L.CAMERA_DTYPE).tobytes(), np.uint8).copy()
+        self.check(lib().rdh_set_camera(self.h, buf.ctypes.data))
+        self.width, self.height = (int(v) for v in cam["resolution"])
+
+    def set_partition(self, rank, world, tile=64):
+        self.check(lib().rdh_set_partition(self.h, rank, world, tile))
+
+    def tiles_per_rank(self):
+        n = lib().rdh_tiles_per_rank(self.h)
+        if n < 0:
+            self.check(n)
+        return n
+
+    def untile(self, gathered, frame):
+        self.check(lib().rdh_untile(self.h, gathered.data_ptr(), frame.data_ptr()))
+
+    # ---- hot path ----
+    def path_trace(self, direct, indirect, iter, looper, max_depth, flags=RDH_PT_MEGAKERNEL):
+        self.check(lib().rdh_path_trace(self.h, direct.data_ptr(), indirect.data_ptr(), iter, looper, max_depth, flags))
+
+    def path_trace_direct(self, direct, iter, looper, flags=0):
+        self.check(lib().rdh_path_trace_direct(self.h, direct.data_ptr(), iter, looper, flags))
+
+    def gbuffer_render(self, gb_c, flags=0):
+        self.check(lib().rdh_gbuffer_render(self.h, C.byref(gb_c), flags))
+
+    def restir_init(self):
+        self.check(lib().rdh_restir_init(self.h))
+
+    def restir_free(self):
+        self.check(lib().rdh_restir_free(self.h))
+
+    def restir_direct(self, direct, iter, looper, gb_c, reuse_mask, ris_count=32, num_spatial=5, temporal_clamp=20,
+                      faithful_ris=1, flags=0):
+        p = RestirParamsC(reuse_mask, ris_count, num_spatial, temporal_clamp, faithful_ris)
+        self.check(lib().rdh_restir_direct(self.h, direct.data_ptr(), iter, looper, C.byref(gb_c), C.byref(p), flags))
+
+    def restir_read(self, which):
+        out = np.zeros(self.width * self.height, dtype=L.RESERVOIR_DTYPE)
+        self.check(lib().rdh_restir_read(self.h, which, out.ctypes.data))
+        return out
+
+    def trace_closest(self, rays, hits, flags=0):
+        self.check(lib().rdh_trace_closest(self.h, rays.data_ptr(), rays.numel() // 6, hits.data_ptr(), flags))
+
+    def trace_occluded(self, segments, out, flags=0):
+        self.check(lib().rdh_trace_occluded(self.h, segments.data_ptr(), segments.numel() // 6, out.data_ptr(), flags))
+
+    def counters_reset(self):
+        self.check(lib().rdh_counters_reset(self.h))
+
+    def counters(self):
+        c = CountersC()
+        self.check(lib().rdh_counters_read(self.h, C.byref(c)))
+        return c.as_dict()
+
+    def synchronize(self):
+        self.check(lib().rdh_synchronize(self.h))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self.check(lib().rdh_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+
+# ======================================================================================================================
+# The reference's globals and free functions
+# ======================================================================================================================
+class ReservoirReuse:  # src/common.h:41-48
+    NONE, Temporal, Spatial, TemporalSpatial = 0, 1, 2, 3
+
+
+class Settings:  # src/common.h:50-66, defaults src/common.cpp:3-15
+    traceDepth = 0
+    useReservoir = True
+    reservoirReuse = ReservoirReuse.Temporal
+    accumulate = False
+    # knobs that exist only here (not in the reference)
+    ptFlags = RDH_PT_MEGAKERNEL
+    restirNumSpatial = 5      # src/restir.cu:87
+    restirRISCount = 32       # RESERVOIR_SIZE, src/restir.h:9
+    restirTemporalClamp = 20  # src/restir.cu:168
+    restirFaithfulRIS = 1     # src/restir.h:21
+
+
+class State:  # src/common.h:68-72
+    camChanged = True
+    looper = 0
+    scene = None  # a `Scene` below
+
+
+class DevScene:
+    """`DevScene::create/destroy` (src/scene.h:74-75): owns the device copy of a scene (inside an rdh_ctx)."""
+
+    def __init__(self):
+        self.ctx = None
+
+    def create(self, scene_data, device=0):
+        self.ctx = Context(device)
+        self.ctx.upload_scene(scene_data)
+
+    def destroy(self):
+        if self.ctx:
+            self.ctx.close()
+            self.ctx = None
+
+
+class Scene:
+    """The slice of the reference's `Scene` the render API reads: `camera` and `devScene` (src/scene.h:520-577)."""
+
+    def __init__(self, scene_data, camera, device=0):
+        self.data = scene_data
+        self.camera = camera
+        self.devScene = DevScene()
+        self.devScene.create(scene_data, device)
+
+    def clear(self):  # Scene::clear (src/scene.cpp:251-254)
+        self.devScene.destroy()
+
+
+def _ctx():
+    if State.scene is None or State.scene.devScene.ctx is None:
+        raise RadishError("State.scene is not set")
+    ctx = State.scene.devScene.ctx
+    ctx.set_camera(State.scene.camera)
+    return ctx
+
+
+def _advance_looper():
+    State.looper = (State.looper + 1) % SOBOL_SAMPLE_NUM  # src/pathtrace.cu:380-381
+
+
+def pathTraceInit():  # src/pathtrace.cu:28
+    _ctx().synchronize()
+
+
+def pathTraceFree():  # src/pathtrace.cu:30
+    pass
+
+
+def pathTrace(directIllum, indirectIllum, iter):
+    """src/pathtrace.cu:351-385.  Blocking, like the reference (checkCUDAError = device sync)."""
+    ctx = _ctx()
+    ctx.path_trace(directIllum, indirectIllum, iter, State.looper, Settings.traceDepth, Settings.ptFlags)
+    ctx.synchronize()
+    _advance_looper()
+
+
+def pathTraceDirect(directIllum, iter):
+    """src/pathtrace.cu:387-407."""
+    ctx = _ctx()
+    ctx.path_trace_direct(directIllum, iter, State.looper, Settings.ptFlags & RDH_PT_COUNT)
+    ctx.synchronize()
+    _advance_looper()
+
+
+def ReSTIRInit():  # src/restir.cu:235-245
+    _ctx().restir_init()
+
+
+def ReSTIRFree():  # src/restir.cu:247-251
+    if State.scene is not None and State.scene.devScene.ctx is not None:
+        State.scene.devScene.ctx.restir_free()
+
+
+def ReSTIRDirect(directIllum, iter, gBuffer):
+    """src/restir.cu:205-233 (swap of the reservoir buffers and the first-frame flag happen inside the library)."""
+    ctx = _ctx()
+    ctx.restir_direct(directIllum, iter, State.looper, gBuffer.c_struct(), Settings.reservoirReuse,
+                      Settings.restirRISCount, Settings.restirNumSpatial, Settings.restirTemporalClamp,
+                      Settings.restirFaithfulRIS, Settings.ptFlags & RDH_PT_COUNT)
+    ctx.synchronize()
+    _advance_looper()
+
+
+class GBuffer:
+    """src/gBuffer.h:15-58.  Planes are torch CUDA tensors; `c_struct()` is the 272-byte reference layout."""
+
+    def __init__(self):
+        self.width = self.height = 0
+        self.frameIdx = 0
+        self.lastCam = None
+
+    def create(self, width, height, device=0):  # src/denoiser.cu:329-344
+        torch = _torch()
+        n = width * height
+        dev = torch.device("cuda", device)
+        self.width, self.height = width, height
+        self.albedo = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        self.normal = [torch.zeros(n, 3, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.motion = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.depth = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.primId = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.frameIdx = 0
+        self.lastCam = None
+
+    def destroy(self):  # src/denoiser.cu:346-359
+        for name in ("albedo", "normal", "motion", "depth", "primId"):
+            if hasattr(self, name):
+                delattr(self, name)
+
+    def c_struct(self, cam_fallback=None):
+        g = GBufferC()
+        g.albedo = self.albedo.data_ptr()
+        g.normal = (C.c_void_p * 2)(*[t.data_ptr() for t in self.normal])
+        g.motion = self.motion.data_ptr()
+        g.depth = (C.c_void_p * 2)(*[t.data_ptr() for t in self.depth])
+        g.primId = (C.c_void_p * 2)(*[t.data_ptr() for t in self.primId])
+        g.frameIdx = self.frameIdx
+        last = self.lastCam if self.lastCam is not None else cam_fallback
+        if last is not None:
+            raw = np.asarray(last, dtype=L.CAMERA_DTYPE).tobytes()
+            g.lastCam = (C.c_uint8 * 196)(*raw)
+        g.width, g.height = self.width, self.height
+        return g
+
+    def render(self, devScene, cam):
+        """GBuffer::render (src/gBuffer.cu:83-103).  On the very first frame the reference's lastCam is
+        uninitialised memory; here it is defined to be `cam`."""
+        ctx = devScene.ctx
+        ctx.set_camera(cam)
+        ctx.gbuffer_render(self.c_struct(cam_fallback=cam), Settings.ptFlags & RDH_PT_COUNT)
+        ctx.synchronize()
+
+    def update(self, cam):  # src/gBuffer.cu:78-81
+        self.lastCam = np.asarray(cam, dtype=L.CAMERA_DTYPE).copy()
+        self.frameIdx ^= 1

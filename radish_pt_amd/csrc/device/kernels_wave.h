@@ -1,0 +1,273 @@
+// radish_pt_amd/csrc/device/kernels_wave.h — the wavefront path tracer: raygen → [trace → shade]* → finish.
+//
+// The reference has no counterpart (it is a megakernel); the contract is that every pixel receives
+// exactly the value singleKernelPT (/root/reference/src/pathtrace.cu:149-291) would give it.  That holds because
+//   * the RNG stream depends only on (looper, pixel index, draw count) and its 8-byte state rides with the path;
+//   * each path owns its accumulators (no cross-path atomics), and launches are stream-ordered so that the
+//     additions to `direct`/`indirect` happen in the megakernel's order (NEE of bounce d, then the emitter hit
+//     of bounce d);
+//   * all arithmetic is the same device functions the megakernel calls.
+//
+// Launch structure per frame (maxDepth = D):  memset(counters) · raygen · for k = 0..D { trace(k) · shade(k) } · finish
+//   trace(k)  = any-hit for the shadow rays emitted by shade(k-1)  +  closest-hit for the rays of bounce k
+//   shade(k)  = surface fetch for hit k, emitter/miss termination, then bounce body k+1 (NEE sample → shadow
+//               queue, BSDF sample → next ray queue) with wave64 ballot compaction
+// trace and shade are persistent kernels: a fixed grid of waves pulls 64-item packets from device-side queue
+// heads (one returning atomic per packet), so no queue length ever travels to the host.
+#pragma once
+#include "kernels_pt.h"
+
+namespace rd {
+
+constexpr int kMaxWaveDepth = 32;  // 4 + 7*depth Sobol dimensions <= 200 → depth <= 28
+
+struct WaveCounters {
+    int rayCount[kMaxWaveDepth + 2];     // rays of bounce k (written by raygen / shade(k-1))
+    int shadowCount[kMaxWaveDepth + 2];  // shadow rays emitted by shade(k)
+    int hitCount[kMaxWaveDepth + 2][4];  // hit records of bounce k per shading class
+    int traceHead[kMaxWaveDepth + 2];
+    int shadeHead[kMaxWaveDepth + 2][4];
+};
+
+struct WaveWorkspace {
+    float4 *ro;       // ray origin.xyz (offset applied), w = pdf of the BSDF sample that made this ray
+    float4 *rd;       // ray direction.xyz, w = 1 if that sample was specular (deltaSample)
+    float4 *thr;      // throughput.xyz
+    float4 *prevPos;  // position the ray left from (curPos, pathtrace.cu:227) = origin of the pending shadow ray
+    float4 *accD;     // direct.xyz
+    float4 *accI;     // indirect.xyz
+    float4 *nee;      // pending NEE contribution.xyz, w: 0 → direct, 1 → indirect, -1 → nothing to add
+    float4 *sht;      // shadow-ray target.xyz
+    uint2 *rng;       // {scramble, ptr}
+    int4 *hit;        // {primId, bary.x, bary.y, dist}
+    int *rayq[2];
+    int *shadowq;
+    int *hitq[4];
+    WaveCounters *ctr;
+};
+
+RD_DEV unsigned long long laneMaskLt() { return (1ull << (threadIdx.x & 63u)) - 1ull; }
+
+// Append `item` for every lane with pred==true: one atomic per wave, order inside the wave preserved.
+RD_DEV void waveAppend(bool pred, int item, int *queue, int *count) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(count, __popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (pred) queue[base + __popcll(mask & laneMaskLt())] = item;
+}
+
+// One packet of 64 consecutive items from a shared head.  Returns the first item index for this wave.
+RD_DEV int wavePull(int *head) {
+    int base = 0;
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(head, 64);
+    return __shfl(base, 0, 64);
+}
+
+// ---- raygen ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelMap pm, WaveWorkspace w, int looper) {
+    unsigned wg;
+    bool wgValid = xcdSwizzle(blockIdx.x, (unsigned)(pm.numBlocks + 3) >> 2, wg);
+    unsigned lane = threadIdx.x & 63u;
+    unsigned block = wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u;
+    Pix px = mapPixel(pm, block, lane);
+    bool valid = px.valid && wgValid;
+    int p = int(block * 64u + lane);  // path slot = work index (fixed for the frame)
+    if (valid) {
+        Sampler rng = makeSeededRandomEngine(looper, px.index, 0, s.sobol);
+        Ray ray = cameraSample(cam, px.x, px.y, sample4D(rng));
+        w.ro[p] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.f);
+        w.rd[p] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.f);
+        w.accD[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w.accI[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w.rng[p] = make_uint2(rng.scramble, (unsigned)rng.ptr);
+    }
+    waveAppend(valid, p, w.rayq[0], &w.ctr->rayCount[0]);
+}
+
+// ---- trace(k): shadow rays of bounce k (from shade(k-1)) + closest hits of bounce k ---------------------------
+template <bool COUNT, bool SORT>
+__global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int k) {
+    WaveCounters *c = w.ctr;
+    const int nShadow = (k > 0) ? c->shadowCount[k - 1] : 0;
+    const int nRay = c->rayCount[k];
+    const int total = nShadow + nRay;
+    const int *rayq = w.rayq[k & 1];
+    WalkStats ws{0, 0};
+    unsigned nClosest = 0, nAny = 0, nHits = 0;
+    const int lane = int(threadIdx.x & 63u);
+    for (;;) {
+        int base = wavePull(&c->traceHead[k]);
+        if (base >= total) break;
+        int item = base + lane;
+        bool isShadow = item < nShadow;
+        bool isRay = !isShadow && item < total;
+        int cls = -1;
+        int p = -1;
+        if (isShadow) {
+            p = w.shadowq[item];
+            float4 x = w.prevPos[p], y = w.sht[p];
+            nAny++;
+            bool occ = traceOccluded<COUNT>(s, mk3(x.x, x.y, x.z), mk3(y.x, y.y, y.z), ws);
+            float4 n = w.nee[p];
+            if (!occ && n.w >= 0.f) {
+                if (n.w == 0.f) {
+                    float4 a = w.accD[p];
+                    w.accD[p] = make_float4(a.x + n.x, a.y + n.y, a.z + n.z, 0.f);
+                } else {
+                    float4 a = w.accI[p];
+                    w.accI[p] = make_float4(a.x + n.x, a.y + n.y, a.z + n.z, 0.f);
+                }
+            }
+        } else if (isRay) {
+            p = rayq[item - nShadow];
+            float4 o = w.ro[p], d = w.rd[p];
+            Ray ray{mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z)};
+            nClosest++;
+            HitRec h = traceClosest<COUNT>(s, ray, ws);
+            w.hit[p] = make_int4(h.prim, __float_as_int(h.bary.x), __float_as_int(h.bary.y), __float_as_int(h.dist));
+            cls = 0;
+            if (h.prim != -1) {
+                nHits++;
+                if (SORT) {  // shading class = BSDF type; misses and emitters share class 0 (both terminate)
+                    int matId = __float_as_int(s.tris[h.prim].c.y);
+                    int type = __float_as_int(s.mats[matId].a.x);
+                    cls = (type == Lambertian) ? 1 : (type == MetallicWorkflow ? 2 : (type == Dielectric ? 3 : 0));
+                }
+            }
+        }
+        if (SORT) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) waveAppend(cls == q, p, w.hitq[q], &c->hitCount[k][q]);
+        } else {
+            waveAppend(cls == 0, p, w.hitq[0], &c->hitCount[k][0]);
+        }
+    }
+    if (COUNT) flushCounters(s.counters, nClosest, nAny, nHits, ws);
+}
+
+// ---- shade(k): hit k → terminate or run bounce body k+1 ----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int k, int maxDepth) {
+    WaveCounters *c = w.ctr;
+    const int lane = int(threadIdx.x & 63u);
+    for (int q = 0; q < 4; q++) {
+        const int n = c->hitCount[k][q];
+        const int *hitq = w.hitq[q];
+        for (;;) {
+            int base = wavePull(&c->shadeHead[k][q]);
+            if (base >= n) break;
+            int item = base + lane;
+            bool active = item < n;
+            bool emitShadow = false, emitRay = false;
+            int p = -1;
+            if (active) {
+                p = hitq[item];
+                int4 h = w.hit[p];
+                float4 rdw = w.rd[p];
+                v3 rayDir = mk3(rdw.x, rdw.y, rdw.z);
+                do {
+                    if (h.x == -1) {  // miss: primary → direct = 1 (pathtrace.cu:169-172); later → break (:232-247, no env map)
+                        if (k == 0) w.accD[p] = make_float4(1.f, 1.f, 1.f, 0.f);
+                        break;
+                    }
+                    Surface isec;
+                    fetchSurface(s, h.x, mk2(__int_as_float(h.y), __int_as_float(h.z)), isec);
+                    Material material = loadMaterial(s.mats, isec.matId);
+                    v3 throughput;
+                    if (k == 0) {
+                        material.baseColor = mk3(1.f);  // DENOISER_DEMODULATE (:175-178)
+                        if (material.type == Light) {   // :179-182
+                            w.accD[p] = make_float4(1.f, 1.f, 1.f, 0.f);
+                            break;
+                        }
+                        throughput = mk3(1.f);
+                    } else {
+                        float4 t = w.thr[p];
+                        throughput = mk3(t.x, t.y, t.z);
+                        if (material.type == Light) {  // :251-271
+                            if (dot(isec.norm, rayDir) < 0.f) break;
+                            v3 radiance = material.baseColor;
+                            float4 o = w.ro[p], cp = w.prevPos[p];
+                            bool deltaSample = rdw.w != 0.f;
+                            float weight = deltaSample
+                                               ? 1.f
+                                               : powerHeuristic(o.w, pdfAreaToSolidAngle(luminance(radiance) * s.sumLightPowerInv *
+                                                                                            getPrimitiveArea(s, isec.primId),
+                                                                                        mk3(cp.x, cp.y, cp.z), isec.pos, isec.norm));
+                            v3 add = radiance * throughput * weight;
+                            float4 a = w.accI[p];
+                            w.accI[p] = make_float4(a.x + add.x, a.y + add.y, a.z + add.z, 0.f);
+                            break;
+                        }
+                    }
+                    const int depth = k + 1;
+                    if (depth > maxDepth) break;  // loop bound of pathtrace.cu:187
+                    isec.wo = -rayDir;
+                    bool deltaBSDF = (material.type == Dielectric);
+                    if (material.type != Dielectric && dot(isec.norm, isec.wo) < 0.f) isec.norm = -isec.norm;
+                    uint2 rs = w.rng[p];
+                    Sampler rng{s.sobol, rs.x, (int)rs.y};
+                    if (!deltaBSDF) {  // NEE (:195-208); the shadow ray itself is traced by trace(k+1)
+                        v4 r4 = sample4D(rng);
+                        if (s.lightSamplerLength != 0) {
+                            LightPick lp = pickLightPoint(s, r4);
+                            v3 radiance = mk3(0.f), wi = mk3(0.f);
+                            float lightPdf = lightPdfUnoccluded(s, isec.pos, lp, radiance, wi);
+                            float4 n = make_float4(0.f, 0.f, 0.f, -1.f);
+                            if (lightPdf > 0.f) {
+                                float BSDFPdf = materialPdf(material, isec.norm, isec.wo, wi);
+                                v3 cc = throughput * materialBSDF(material, isec.norm, isec.wo, wi) * radiance *
+                                        satDot(isec.norm, wi) / lightPdf * powerHeuristic(lightPdf, BSDFPdf);
+                                n = make_float4(cc.x, cc.y, cc.z, depth == 1 ? 0.f : 1.f);
+                            }
+                            w.nee[p] = n;
+                            w.sht[p] = make_float4(lp.sampled.x, lp.sampled.y, lp.sampled.z, 0.f);
+                            emitShadow = true;  // traced even when nothing can be added: sampleDirectLight tests
+                                                // occlusion before the single-sided rejection
+                        }
+                    }
+                    w.prevPos[p] = make_float4(isec.pos.x, isec.pos.y, isec.pos.z, 0.f);
+                    BSDFSample sample;
+                    sample.pdf = 0.f;
+                    materialSample(material, isec.norm, isec.wo, sample3D(rng), sample);
+                    if (sample.type == Invalid) break;
+                    else if (sample.pdf < 1e-8f) break;
+                    bool deltaSample = (sample.type & Specular) != 0;
+                    throughput = throughput * (sample.bsdf / sample.pdf * (deltaSample ? 1.f : absDot(isec.norm, sample.dir)));
+                    Ray ray = makeOffsetedRay(isec.pos, sample.dir);
+                    w.ro[p] = make_float4(ray.o.x, ray.o.y, ray.o.z, sample.pdf);
+                    w.rd[p] = make_float4(ray.d.x, ray.d.y, ray.d.z, deltaSample ? 1.f : 0.f);
+                    w.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, 0.f);
+                    w.rng[p] = make_uint2(rng.scramble, (unsigned)rng.ptr);
+                    emitRay = true;
+                } while (false);
+            }
+            waveAppend(emitShadow, p, w.shadowq, &c->shadowCount[k]);
+            waveAppend(emitRay, p, w.rayq[(k + 1) & 1], &c->rayCount[k + 1]);
+        }
+    }
+}
+
+// ---- finish: NaN scrub, HDRToLDR, running mean (pathtrace.cu:279-290) ------------------------------------------
+__global__ __launch_bounds__(256) void k_wf_finish(PixelMap pm, WaveWorkspace w, int iter, float *__restrict__ directIllum,
+                                                   float *__restrict__ indirectIllum) {
+    unsigned wg;
+    bool wgValid = xcdSwizzle(blockIdx.x, (unsigned)(pm.numBlocks + 3) >> 2, wg);
+    unsigned lane = threadIdx.x & 63u;
+    unsigned block = wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u;
+    Pix px = mapPixel(pm, block, lane);
+    if (!(px.valid && wgValid)) return;
+    int p = int(block * 64u + lane);
+    float4 a = w.accD[p], b = w.accI[p];
+    v3 direct = mk3(a.x, a.y, a.z), indirect = mk3(b.x, b.y, b.z);
+    if (hasNanOrInf(direct)) direct = mk3(0.f);
+    if (hasNanOrInf(indirect)) indirect = mk3(0.f);
+    direct = HDRToLDR(direct);
+    indirect = HDRToLDR(indirect);
+    storeRunningMean(directIllum, px.out, direct, iter);
+    storeRunningMean(indirectIllum, px.out, indirect, iter);
+}
+
+}  // namespace rd

@@ -1,0 +1,99 @@
+// radish_pt_amd/csrc/device/layouts.h — HBM layout of the scene as the gfx950 kernels read it.
+//
+// The reference keeps the scene as AoS glm::vec3 arrays plus a 12-byte node that points into a separate AABB
+// array (src/scene.h:494-517, src/bvh.h:161-170): every traversal step is two dependent, unaligned gathers.
+// rdh_scene_upload re-lays it out so that each step is ONE aligned 32-byte record (two dwordx4 loads) and each
+// triangle test is ONE aligned 48-byte record; nothing here changes a value — records are byte copies of the
+// reference's floats/ints, only their placement differs.
+#pragma once
+#include "rmath.h"
+
+namespace rd {
+
+// One threaded-BVH step: box + leaf primitive + miss link.  32 B, 32-B aligned.  Six arrays (one per ordering,
+// src/bvh.cpp:136-183), each bvhSize records in traversal order.
+struct __attribute__((aligned(16))) NodeRec {
+    float4 lo_prim;  // pMin.xyz, primitiveId (int bits; -1 = inner node)
+    float4 hi_next;  // pMax.xyz, nextNodeIfMiss (int bits)
+};
+static_assert(sizeof(NodeRec) == 32, "NodeRec");
+
+// One triangle: the three vertices exactly as in `vertices[3*prim+{0,1,2}]` + the material id.  48 B.
+struct __attribute__((aligned(16))) TriRec {
+    float4 a;  // va.xyz, vb.x
+    float4 b;  // vb.yz, vc.xy
+    float4 c;  // vc.z, materialId (int bits), 0, 0
+};
+static_assert(sizeof(TriRec) == 48, "TriRec");
+
+// Shading attributes of one triangle (read once per closest hit): normals + texcoords.  64 B.
+struct __attribute__((aligned(16))) AttrRec {
+    float4 a;  // na.xyz, nb.x
+    float4 b;  // nb.yz, nc.xy
+    float4 c;  // nc.z, ta.xy, tb.x
+    float4 d;  // tb.y, tc.xy, 0
+};
+static_assert(sizeof(AttrRec) == 64, "AttrRec");
+
+// One emissive triangle, indexed by light id (folds lightPrimIds → vertices and lightUnitRadiance).  48 B.
+struct __attribute__((aligned(16))) LightRec {
+    float4 a;  // v0.xyz, v1.x
+    float4 b;  // v1.yz, v2.xy
+    float4 c;  // v2.z, radiance.xyz
+};
+static_assert(sizeof(LightRec) == 48, "LightRec");
+
+// Material without texture ids (round-1 scope).  32 B.
+struct __attribute__((aligned(16))) MatRec {
+    float4 a;  // type (int bits), baseColor.xyz
+    float4 b;  // metallic, roughness, ior, 0
+};
+
+struct AliasRec {  // BinomialDistrib<float> (src/sampler.h:66-69), unchanged
+    float prob;
+    int failId;
+};
+
+struct Counters {
+    unsigned long long closestRays, anyRays, nodeVisits, triTests, closestHits;
+};
+
+struct DScene {
+    const NodeRec *nodes[6];
+    const TriRec *tris;
+    const AttrRec *attrs;
+    const MatRec *mats;
+    const LightRec *lights;
+    const AliasRec *lightAlias;
+    const uint32_t *sobol;
+    Counters *counters;
+    int bvhSize;
+    int numPrims;
+    int lightSamplerLength;
+    float sumLightPowerInv;
+};
+
+// Camera fields the kernels use (src/sceneStructs.h:118-130), plus tan(radians(fov.y)) hoisted to the host
+// (the reference re-evaluates it per thread, :75).
+struct DCamera {
+    int resx, resy;
+    v3 position, view, up, right;
+    m3 rotationMatInv;
+    float lensRadius, focalDist;
+    float tanFovY;  // tanf(radians(fov.y)) — NOT the struct's tanFovY field, which the kernels never read
+};
+
+// Which pixels this launch renders and where they are stored (single GPU: the whole frame in frame layout;
+// multi-GPU: this rank's interleaved tiles in a packed tile-major buffer).
+struct PixelMap {
+    int W, H;
+    int tile;          // tile edge in pixels (multiple of 8)
+    int tilesX;        // tiles per frame row
+    int numTiles;      // tiles in the frame
+    int rank, world;
+    int tilesPerRank;  // ceil(numTiles / world)
+    int packed;        // 0: out index = y*W+x ; 1: out index = (localTile*tile*tile + ly*tile + lx)
+    int numBlocks;     // 8x8-pixel blocks (= waves) of work in this launch
+};
+
+}  // namespace rd

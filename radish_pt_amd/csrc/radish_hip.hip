@@ -1,0 +1,612 @@
+// radish_pt_amd/csrc/radish_hip.hip — C ABI (include/radish_hip.h) over the gfx950 kernels.
+//
+// Host side of the hot path: scene re-layout + upload (replaces DevScene::create, /root/reference/src/scene.cpp:461-551),
+// launch wrappers (replace pathTrace / pathTraceDirect / GBuffer::render / ReSTIRInit|Free|Direct,
+// /root/reference/src/pathtrace.cu:351-407, gBuffer.cu:83-103, restir.cu:205-251).  There is no CPU fallback: without a
+// HIP device rdh_create fails with RDH_ERR_NO_DEVICE.
+#include "radish_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device/kernels_pt.h"
+#include "device/kernels_restir.h"
+#include "device/kernels_wave.h"
+
+using namespace rd;
+
+struct rdh_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool timed = false;
+    std::string err;
+
+    // scene
+    bool haveScene = false;
+    DScene ds{};
+    std::vector<void *> sceneAllocs;
+    Counters *dCounters = nullptr;
+
+    // camera
+    bool haveCamera = false;
+    DCamera cam{};
+
+    // partition
+    int rank = 0, world = 1, tile = 64;
+
+    // ReSTIR buffers (restir.cu:4-7)
+    float *resvCur = nullptr, *resvLast = nullptr, *resvTemp = nullptr;
+    float4 *restirState = nullptr;
+    long long restirPixels = 0;
+    bool restirFirstFrame = true;
+
+    // wavefront workspace
+    WaveWorkspace wf{};
+    long long wfCapacity = 0;
+    std::vector<void *> wfAllocs;
+};
+
+namespace {
+
+int fail(rdh_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((c), (int)e_, "HIP error (%s:%d): %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int uploadVec(rdh_ctx *c, const std::vector<T> &v, const T **out) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    c->sceneAllocs.push_back(p);
+    if (!v.empty()) HIP_TRY(c, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(p);
+    return RDH_OK;
+}
+
+float asFloat(int32_t i) {
+    float f;
+    memcpy(&f, &i, 4);
+    return f;
+}
+
+struct HostCamera {  // src/sceneStructs.h:118-130
+    int32_t resx, resy;
+    float position[3], rotation[3], view[3], up[3], right[3];
+    float fov[2], pixelLength[2];
+    float rotationMatInv[9];
+    float viewProjection[16];
+    float lensRadius, focalDist, tanFovY;
+};
+static_assert(sizeof(HostCamera) == 196, "Camera layout");
+
+DCamera toDeviceCamera(const void *camera196) {
+    HostCamera h;
+    memcpy(&h, camera196, sizeof(h));
+    DCamera d;
+    d.resx = h.resx;
+    d.resy = h.resy;
+    d.position = {h.position[0], h.position[1], h.position[2]};
+    d.view = {h.view[0], h.view[1], h.view[2]};
+    d.up = {h.up[0], h.up[1], h.up[2]};
+    d.right = {h.right[0], h.right[1], h.right[2]};
+    d.rotationMatInv.c0 = {h.rotationMatInv[0], h.rotationMatInv[1], h.rotationMatInv[2]};
+    d.rotationMatInv.c1 = {h.rotationMatInv[3], h.rotationMatInv[4], h.rotationMatInv[5]};
+    d.rotationMatInv.c2 = {h.rotationMatInv[6], h.rotationMatInv[7], h.rotationMatInv[8]};
+    d.lensRadius = h.lensRadius;
+    d.focalDist = h.focalDist;
+    // glm::tan(glm::radians(fov.y)) (sceneStructs.h:75), hoisted to the host: libm tanf of (deg * pi/180)
+    d.tanFovY = tanf(h.fov[1] * 0.01745329251994329576923690768489f);
+    return d;
+}
+
+PixelMap makePixelMap(const rdh_ctx *c) {
+    PixelMap pm;
+    pm.W = c->cam.resx;
+    pm.H = c->cam.resy;
+    pm.tile = c->tile;
+    pm.tilesX = (pm.W + pm.tile - 1) / pm.tile;
+    int tilesY = (pm.H + pm.tile - 1) / pm.tile;
+    pm.numTiles = pm.tilesX * tilesY;
+    pm.rank = c->rank;
+    pm.world = c->world;
+    pm.tilesPerRank = (pm.numTiles + pm.world - 1) / pm.world;
+    pm.packed = c->world > 1 ? 1 : 0;
+    int bpe = pm.tile / 8;
+    pm.numBlocks = pm.tilesPerRank * bpe * bpe;
+    return pm;
+}
+
+// Grid for "4 waves per workgroup, one 8x8 block per wave", padded to a multiple of 8 workgroups (xcdSwizzle).
+unsigned gridFor(const PixelMap &pm) {
+    unsigned work = (unsigned)(pm.numBlocks + 3) / 4;
+    return ((work + 7u) / 8u) * 8u;
+}
+
+int requireReady(rdh_ctx *c) {
+    if (!c) return RDH_ERR_ARGS;
+    if (!c->haveScene) return fail(c, RDH_ERR_NO_SCENE, "no scene uploaded (rdh_scene_upload)");
+    if (!c->haveCamera) return fail(c, RDH_ERR_NO_SCENE, "no camera set (rdh_set_camera)");
+    return RDH_OK;
+}
+
+// Persistent kernels: enough workgroups to fill every CU at full occupancy; surplus ones find the queues empty.
+constexpr unsigned kPersistentGrid = 256u * 8u;
+
+template <typename T>
+int wfAlloc(rdh_ctx *c, T **out, size_t count) {
+    void *p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+    c->wfAllocs.push_back(p);
+    *out = static_cast<T *>(p);
+    return RDH_OK;
+}
+
+// Workspace for the wavefront pipeline: 152 B of path state + 7 queue slots per path slot.
+int wavefrontEnsure(rdh_ctx *c, const PixelMap &pm) {
+    long long slots = (long long)pm.numBlocks * 64;
+    if (c->wfCapacity >= slots) return RDH_OK;
+    for (void *p : c->wfAllocs) hipFree(p);
+    c->wfAllocs.clear();
+    c->wfCapacity = 0;
+    WaveWorkspace &w = c->wf;
+    int rc;
+    size_t n = (size_t)slots;
+    if ((rc = wfAlloc(c, &w.ro, n)) || (rc = wfAlloc(c, &w.rd, n)) || (rc = wfAlloc(c, &w.thr, n)) ||
+        (rc = wfAlloc(c, &w.prevPos, n)) || (rc = wfAlloc(c, &w.accD, n)) || (rc = wfAlloc(c, &w.accI, n)) ||
+        (rc = wfAlloc(c, &w.nee, n)) || (rc = wfAlloc(c, &w.sht, n)) || (rc = wfAlloc(c, &w.rng, n)) ||
+        (rc = wfAlloc(c, &w.hit, n)) || (rc = wfAlloc(c, &w.rayq[0], n)) || (rc = wfAlloc(c, &w.rayq[1], n)) ||
+        (rc = wfAlloc(c, &w.shadowq, n)) || (rc = wfAlloc(c, &w.hitq[0], n)) || (rc = wfAlloc(c, &w.hitq[1], n)) ||
+        (rc = wfAlloc(c, &w.hitq[2], n)) || (rc = wfAlloc(c, &w.hitq[3], n)) || (rc = wfAlloc(c, &w.ctr, 1)))
+        return rc;
+    c->wfCapacity = slots;
+    return RDH_OK;
+}
+
+int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d_indirect, int iter, int looper,
+                       int maxDepth, uint32_t flags) {
+    if (maxDepth > kMaxWaveDepth) return fail(c, RDH_ERR_ARGS, "maxDepth %d exceeds %d", maxDepth, kMaxWaveDepth);
+    const bool count = (flags & RDH_PT_COUNT) != 0, sort = (flags & RDH_PT_SORT_MATERIAL) != 0;
+    WaveWorkspace &w = c->wf;
+    HIP_TRY(c, hipMemsetAsync(w.ctr, 0, sizeof(WaveCounters), c->stream));
+    hipLaunchKernelGGL(k_wf_raygen, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, w, looper);
+    for (int k = 0; k <= maxDepth; k++) {
+        if (count && sort) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
+        else if (count) hipLaunchKernelGGL((k_wf_trace<true, false>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
+        else if (sort) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
+        else hipLaunchKernelGGL((k_wf_trace<false, false>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
+        hipLaunchKernelGGL(k_wf_shade, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k, maxDepth);
+    }
+    hipLaunchKernelGGL(k_wf_finish, dim3(gridFor(pm)), dim3(256), 0, c->stream, pm, w, iter, d_direct, d_indirect);
+    return RDH_OK;
+}
+
+void timeBegin(rdh_ctx *c) {
+    hipEventRecord(c->evStart, c->stream);
+}
+int timeEnd(rdh_ctx *c, const char *what) {
+    hipEventRecord(c->evStop, c->stream);
+    c->timed = true;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, (int)e, "HIP error: %s: %s", what, hipGetErrorString(e));
+    return RDH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rdh_create(rdh_ctx **out, int device) {
+    if (!out) return RDH_ERR_ARGS;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return RDH_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RDH_ERR_NO_DEVICE;
+    rdh_ctx *c = new rdh_ctx;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
+        hipMalloc((void **)&c->dCounters, sizeof(Counters)) != hipSuccess) {
+        delete c;
+        return RDH_ERR_NO_DEVICE;
+    }
+    hipMemset(c->dCounters, 0, sizeof(Counters));
+    c->stream = c->ownStream;
+    *out = c;
+    return RDH_OK;
+}
+
+int rdh_scene_free(rdh_ctx *c) {
+    if (!c) return RDH_ERR_ARGS;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (void *p : c->sceneAllocs) hipFree(p);
+    c->sceneAllocs.clear();
+    c->haveScene = false;
+    return RDH_OK;
+}
+
+void rdh_destroy(rdh_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    rdh_scene_free(c);
+    rdh_restir_free(c);
+    for (void *p : c->wfAllocs) hipFree(p);
+    if (c->dCounters) hipFree(c->dCounters);
+    if (c->evStart) hipEventDestroy(c->evStart);
+    if (c->evStop) hipEventDestroy(c->evStop);
+    if (c->ownStream) hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+const char *rdh_last_error(const rdh_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int rdh_set_stream(rdh_ctx *c, void *s) {
+    if (!c) return RDH_ERR_ARGS;
+    c->stream = s ? static_cast<hipStream_t>(s) : c->ownStream;
+    return RDH_OK;
+}
+
+int rdh_synchronize(rdh_ctx *c) {
+    if (!c) return RDH_ERR_ARGS;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RDH_OK;
+}
+
+int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
+    if (!c || !d) return RDH_ERR_ARGS;
+    if (!d->vertices || !d->normals || !d->texcoords || !d->boundingBoxes || !d->materialIds || !d->materials ||
+        !d->sampleSequence || d->numPrims <= 0 || d->bvhSize != 2 * d->numPrims - 1 || d->numMaterials <= 0)
+        return fail(c, RDH_ERR_ARGS, "rdh_scene_upload: inconsistent descriptor");
+    for (int k = 0; k < 6; k++)
+        if (!d->bvhNodes[k]) return fail(c, RDH_ERR_ARGS, "rdh_scene_upload: bvhNodes[%d] is null", k);
+    if (d->lightSamplerLength > 0 && (!d->lightSampler || !d->lightPrimIds || !d->lightUnitRadiance))
+        return fail(c, RDH_ERR_ARGS, "rdh_scene_upload: light arrays missing");
+    if (d->lightSamplerLength != d->numLights)
+        return fail(c, RDH_ERR_UNSUPPORTED, "environment-map light entry is not supported yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    rdh_scene_free(c);
+
+    struct HostMaterial { int32_t type; float color[3]; float metallic, roughness, ior; int32_t map[4]; };
+    static_assert(sizeof(HostMaterial) == 44, "Material layout");
+    const HostMaterial *hm = static_cast<const HostMaterial *>(d->materials);
+    std::vector<MatRec> mats(d->numMaterials);
+    for (int i = 0; i < d->numMaterials; i++) {
+        if (hm[i].map[0] != -1 || hm[i].map[1] != -1 || hm[i].map[2] > -1 || hm[i].map[3] > -1)
+            return fail(c, RDH_ERR_UNSUPPORTED, "material %d uses textures: not supported yet", i);
+        mats[i].a = make_float4(asFloat(hm[i].type), hm[i].color[0], hm[i].color[1], hm[i].color[2]);
+        mats[i].b = make_float4(hm[i].metallic, hm[i].roughness, hm[i].ior, 0.f);
+    }
+
+    const int N = d->numPrims, S = d->bvhSize;
+    std::vector<TriRec> tris(N);
+    std::vector<AttrRec> attrs(N);
+    for (int p = 0; p < N; p++) {
+        const float *v = d->vertices + 9 * (size_t)p;
+        const float *n = d->normals + 9 * (size_t)p;
+        const float *t = d->texcoords + 6 * (size_t)p;
+        int mid = d->materialIds[p];
+        if (mid < 0 || mid >= d->numMaterials) return fail(c, RDH_ERR_ARGS, "materialIds[%d] = %d out of range", p, mid);
+        tris[p].a = make_float4(v[0], v[1], v[2], v[3]);
+        tris[p].b = make_float4(v[4], v[5], v[6], v[7]);
+        tris[p].c = make_float4(v[8], asFloat(mid), 0.f, 0.f);
+        attrs[p].a = make_float4(n[0], n[1], n[2], n[3]);
+        attrs[p].b = make_float4(n[4], n[5], n[6], n[7]);
+        attrs[p].c = make_float4(n[8], t[0], t[1], t[2]);
+        attrs[p].d = make_float4(t[3], t[4], t[5], 0.f);
+    }
+    int rc;
+    if ((rc = uploadVec(c, tris, &c->ds.tris))) return rc;
+    if ((rc = uploadVec(c, attrs, &c->ds.attrs))) return rc;
+    if ((rc = uploadVec(c, mats, &c->ds.mats))) return rc;
+
+    std::vector<NodeRec> nodes(S);
+    for (int k = 0; k < 6; k++) {
+        const int32_t *src = d->bvhNodes[k];
+        for (int i = 0; i < S; i++) {
+            int prim = src[3 * i], box = src[3 * i + 1], next = src[3 * i + 2];
+            if (box < 0 || box >= S || next < 0 || next > S || prim < -1 || prim >= N || next <= i)
+                return fail(c, RDH_ERR_ARGS, "bvhNodes[%d][%d] = {%d,%d,%d} is not a valid threaded node", k, i, prim, box, next);
+            const float *b = d->boundingBoxes + 6 * (size_t)box;
+            nodes[i].lo_prim = make_float4(b[0], b[1], b[2], asFloat(prim));
+            nodes[i].hi_next = make_float4(b[3], b[4], b[5], asFloat(next));
+        }
+        if ((rc = uploadVec(c, nodes, &c->ds.nodes[k]))) return rc;
+    }
+
+    std::vector<LightRec> lights(d->numLights);
+    for (int i = 0; i < d->numLights; i++) {
+        int p = d->lightPrimIds[i];
+        if (p < 0 || p >= N) return fail(c, RDH_ERR_ARGS, "lightPrimIds[%d] = %d out of range", i, p);
+        const float *v = d->vertices + 9 * (size_t)p;
+        const float *r = d->lightUnitRadiance + 3 * (size_t)i;
+        lights[i].a = make_float4(v[0], v[1], v[2], v[3]);
+        lights[i].b = make_float4(v[4], v[5], v[6], v[7]);
+        lights[i].c = make_float4(v[8], r[0], r[1], r[2]);
+    }
+    if ((rc = uploadVec(c, lights, &c->ds.lights))) return rc;
+    std::vector<AliasRec> alias(d->lightSamplerLength);
+    if (d->lightSamplerLength) memcpy(alias.data(), d->lightSampler, sizeof(AliasRec) * alias.size());
+    for (auto &e : alias)
+        if (e.failId < 0 || e.failId >= d->lightSamplerLength) return fail(c, RDH_ERR_ARGS, "alias table failId out of range");
+    if ((rc = uploadVec(c, alias, &c->ds.lightAlias))) return rc;
+    std::vector<uint32_t> sobol(d->sampleSequence, d->sampleSequence + 10000 * 200);
+    if ((rc = uploadVec(c, sobol, &c->ds.sobol))) return rc;
+
+    c->ds.counters = c->dCounters;
+    c->ds.bvhSize = S;
+    c->ds.numPrims = N;
+    c->ds.lightSamplerLength = d->lightSamplerLength;
+    c->ds.sumLightPowerInv = d->sumLightPowerInv;
+    c->haveScene = true;
+    return RDH_OK;
+}
+
+int rdh_set_camera(rdh_ctx *c, const void *camera196) {
+    if (!c || !camera196) return RDH_ERR_ARGS;
+    DCamera d = toDeviceCamera(camera196);
+    if (d.resx <= 0 || d.resy <= 0) return fail(c, RDH_ERR_ARGS, "camera resolution %dx%d", d.resx, d.resy);
+    c->cam = d;
+    c->haveCamera = true;
+    return RDH_OK;
+}
+
+int rdh_set_partition(rdh_ctx *c, int rank, int world, int tileSize) {
+    if (!c || world < 1 || rank < 0 || rank >= world || tileSize < 8 || (tileSize % 8) != 0)
+        return fail(c, RDH_ERR_ARGS, "rdh_set_partition(rank=%d, world=%d, tile=%d)", rank, world, tileSize);
+    c->rank = rank;
+    c->world = world;
+    c->tile = tileSize;
+    return RDH_OK;
+}
+
+int rdh_tiles_per_rank(const rdh_ctx *c) {
+    if (!c || !c->haveCamera) return RDH_ERR_NO_SCENE;
+    return makePixelMap(c).tilesPerRank;
+}
+
+int rdh_untile(rdh_ctx *c, const float *d_gathered, float *d_frame) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_gathered || !d_frame) return fail(c, RDH_ERR_ARGS, "rdh_untile: null buffer");
+    PixelMap pm = makePixelMap(c);
+    long long total = (long long)pm.W * pm.H;
+    hipLaunchKernelGGL(k_untile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_gathered, d_frame, pm.W,
+                       pm.H, pm.tile, pm.tilesX, pm.numTiles, pm.world, pm.tilesPerRank);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int looper, int maxDepth, uint32_t flags) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_direct || !d_indirect || iter < 0 || looper < 0 || looper >= 10000 || maxDepth < 0)
+        return fail(c, RDH_ERR_ARGS, "rdh_path_trace: bad arguments");
+    if (4 + 7 * maxDepth > 200) return fail(c, RDH_ERR_ARGS, "maxDepth %d needs more than 200 Sobol dimensions", maxDepth);
+    HIP_TRY(c, hipSetDevice(c->device));
+    PixelMap pm = makePixelMap(c);
+    const bool count = (flags & RDH_PT_COUNT) != 0;
+    if (flags & RDH_PT_WAVEFRONT) {
+        rc = wavefrontEnsure(c, pm);
+        if (rc) return rc;
+        timeBegin(c);
+        rc = wavefrontPathTrace(c, pm, d_direct, d_indirect, iter, looper, maxDepth, flags);
+        if (rc) return rc;
+        return timeEnd(c, "pathTrace (wavefront)");
+    }
+    timeBegin(c);
+    if (count)
+        hipLaunchKernelGGL(k_path_trace_mega<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
+                           iter, maxDepth, d_direct, d_indirect);
+    else
+        hipLaunchKernelGGL(k_path_trace_mega<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
+                           iter, maxDepth, d_direct, d_indirect);
+    return timeEnd(c, "pathTrace");
+}
+
+int rdh_path_trace_direct(rdh_ctx *c, float *d_direct, int iter, int looper, uint32_t flags) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_direct || iter < 0 || looper < 0 || looper >= 10000) return fail(c, RDH_ERR_ARGS, "rdh_path_trace_direct: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    PixelMap pm = makePixelMap(c);
+    timeBegin(c);
+    if (flags & RDH_PT_COUNT)
+        hipLaunchKernelGGL(k_path_trace_direct<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
+                           iter, d_direct);
+    else
+        hipLaunchKernelGGL(k_path_trace_direct<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
+                           iter, d_direct);
+    return timeEnd(c, "pathTraceDirect");
+}
+
+int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!gb || !gb->albedo || !gb->motion || (gb->frameIdx & ~1)) return fail(c, RDH_ERR_ARGS, "rdh_gbuffer_render: bad G-buffer");
+    for (int k = 0; k < 2; k++)
+        if (!gb->normal[k] || !gb->depth[k] || !gb->primId[k]) return fail(c, RDH_ERR_ARGS, "rdh_gbuffer_render: null plane");
+    if (gb->width != c->cam.resx || gb->height != c->cam.resy)
+        return fail(c, RDH_ERR_ARGS, "G-buffer %dx%d does not match camera %dx%d", gb->width, gb->height, c->cam.resx, c->cam.resy);
+    if (c->world > 1) return fail(c, RDH_ERR_UNSUPPORTED, "G-buffer rendering is per-frame (world must be 1)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    PixelMap pm = makePixelMap(c);
+    DCamera last = toDeviceCamera(gb->lastCam);
+    GBufPtrs p{gb->albedo, gb->normal[gb->frameIdx], gb->motion, gb->depth[gb->frameIdx], gb->primId[gb->frameIdx],
+               gb->width, gb->height};
+    timeBegin(c);
+    if (flags & RDH_PT_COUNT)
+        hipLaunchKernelGGL(k_gbuffer<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p);
+    else
+        hipLaunchKernelGGL(k_gbuffer<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p);
+    return timeEnd(c, "renderGBuffer");
+}
+
+int rdh_restir_free(rdh_ctx *c) {
+    if (!c) return RDH_ERR_ARGS;
+    hipSetDevice(c->device);
+    if (c->resvCur) hipFree(c->resvCur);
+    if (c->resvLast) hipFree(c->resvLast);
+    if (c->resvTemp) hipFree(c->resvTemp);
+    if (c->restirState) hipFree(c->restirState);
+    c->resvCur = c->resvLast = c->resvTemp = nullptr;
+    c->restirState = nullptr;
+    c->restirPixels = 0;
+    return RDH_OK;
+}
+
+int rdh_restir_init(rdh_ctx *c) {
+    if (!c) return RDH_ERR_ARGS;
+    if (!c->haveCamera) return fail(c, RDH_ERR_NO_SCENE, "rdh_restir_init needs the camera resolution (rdh_set_camera)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    rdh_restir_free(c);
+    long long n = (long long)c->cam.resx * c->cam.resy;
+    size_t bytes = (size_t)n * 36;
+    HIP_TRY(c, hipMalloc((void **)&c->resvCur, bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->resvLast, bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->resvTemp, bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->restirState, (size_t)n * 48));
+    HIP_TRY(c, hipMemsetAsync(c->resvCur, 0, bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->resvLast, 0, bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->resvTemp, 0, bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->restirState, 0, (size_t)n * 48, c->stream));
+    c->restirPixels = n;
+    c->restirFirstFrame = true;
+    return RDH_OK;
+}
+
+int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const rdh_gbuffer *gb, const rdh_restir_params *p,
+                      uint32_t flags) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_direct || !gb || !p || iter < 0 || looper < 0 || looper >= 10000) return fail(c, RDH_ERR_ARGS, "rdh_restir_direct: bad arguments");
+    if (!c->resvCur || c->restirPixels != (long long)c->cam.resx * c->cam.resy)
+        return fail(c, RDH_ERR_STATE, "rdh_restir_direct before rdh_restir_init (or resolution changed)");
+    if (gb->width != c->cam.resx || gb->height != c->cam.resy) return fail(c, RDH_ERR_ARGS, "G-buffer size mismatch");
+    if (c->world > 1) return fail(c, RDH_ERR_UNSUPPORTED, "ReSTIR tile partition is not built yet (world must be 1)");
+    if (p->risCount < 0 || p->numSpatial < 0 || p->temporalClamp < 1) return fail(c, RDH_ERR_ARGS, "bad ReSTIR parameters");
+    int dims = 4 + p->risCount * 5 + 1 + ((p->reuseMask & 1) ? 1 : 0) + ((p->reuseMask & 2) ? p->numSpatial * 3 + 1 : 0);
+    if (dims > 200) return fail(c, RDH_ERR_ARGS, "ReSTIR parameters need %d Sobol dimensions (max 200)", dims);
+    HIP_TRY(c, hipSetDevice(c->device));
+    PixelMap pm = makePixelMap(c);
+    int f = gb->frameIdx & 1;
+    RestirArgs a;
+    a.reservoirOut = c->resvCur;
+    a.reservoirIn = c->resvLast;
+    a.reservoirTemp = c->resvTemp;
+    a.state = c->restirState;
+    a.albedo = gb->albedo;
+    a.normalCur = gb->normal[f];
+    a.normalLast = gb->normal[f ^ 1];
+    a.depthCur = gb->depth[f];
+    a.motion = gb->motion;
+    a.primIdCur = gb->primId[f];
+    a.primIdLast = gb->primId[f ^ 1];
+    a.gbWidth = gb->width;
+    a.gbHeight = gb->height;
+    a.firstFrame = c->restirFirstFrame ? 1 : 0;
+    a.reuseMask = p->reuseMask;
+    a.risCount = p->risCount;
+    a.numSpatial = p->numSpatial;
+    a.temporalClamp = p->temporalClamp;
+    a.faithfulRIS = p->faithfulRIS;
+    timeBegin(c);
+    if (flags & RDH_PT_COUNT)
+        hipLaunchKernelGGL(k_restir_pass1<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct);
+    else
+        hipLaunchKernelGGL(k_restir_pass1<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct);
+    if (p->reuseMask & 2)
+        hipLaunchKernelGGL(k_restir_pass2, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, pm, iter, a, d_direct);
+    rc = timeEnd(c, "ReSTIR Direct");
+    std::swap(c->resvCur, c->resvLast);  // restir.cu:221
+    c->restirFirstFrame = false;         // :223-225
+    return rc;
+}
+
+int rdh_restir_read(rdh_ctx *c, int which, void *hostOut) {
+    if (!c || !hostOut || which < 0 || which > 2) return RDH_ERR_ARGS;
+    if (!c->resvCur) return fail(c, RDH_ERR_STATE, "ReSTIR not initialised");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const float *src = which == 0 ? c->resvCur : (which == 1 ? c->resvLast : c->resvTemp);
+    HIP_TRY(c, hipMemcpy(hostOut, src, (size_t)c->restirPixels * 36, hipMemcpyDeviceToHost));
+    return RDH_OK;
+}
+
+int rdh_trace_closest(rdh_ctx *c, const float *d_rays, int64_t n, rdh_hit *d_hits, uint32_t flags) {
+    if (!c) return RDH_ERR_ARGS;
+    if (!c->haveScene) return fail(c, RDH_ERR_NO_SCENE, "no scene uploaded");
+    if (n < 0 || (n > 0 && (!d_rays || !d_hits))) return fail(c, RDH_ERR_ARGS, "rdh_trace_closest: bad arguments");
+    if (n == 0) return RDH_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned grid = (unsigned)((n + 255) / 256);
+    timeBegin(c);
+    if (flags & RDH_PT_COUNT)
+        hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(256), 0, c->stream, c->ds, d_rays, (long long)n, (int4 *)d_hits);
+    else
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(256), 0, c->stream, c->ds, d_rays, (long long)n, (int4 *)d_hits);
+    return timeEnd(c, "trace_closest");
+}
+
+int rdh_trace_occluded(rdh_ctx *c, const float *d_seg, int64_t n, int32_t *d_occ, uint32_t flags) {
+    if (!c) return RDH_ERR_ARGS;
+    if (!c->haveScene) return fail(c, RDH_ERR_NO_SCENE, "no scene uploaded");
+    if (n < 0 || (n > 0 && (!d_seg || !d_occ))) return fail(c, RDH_ERR_ARGS, "rdh_trace_occluded: bad arguments");
+    if (n == 0) return RDH_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned grid = (unsigned)((n + 255) / 256);
+    timeBegin(c);
+    if (flags & RDH_PT_COUNT)
+        hipLaunchKernelGGL(k_trace_occluded<true>, dim3(grid), dim3(256), 0, c->stream, c->ds, d_seg, (long long)n, d_occ);
+    else
+        hipLaunchKernelGGL(k_trace_occluded<false>, dim3(grid), dim3(256), 0, c->stream, c->ds, d_seg, (long long)n, d_occ);
+    return timeEnd(c, "trace_occluded");
+}
+
+int rdh_counters_reset(rdh_ctx *c) {
+    if (!c) return RDH_ERR_ARGS;
+    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, sizeof(Counters), c->stream));
+    return RDH_OK;
+}
+
+int rdh_counters_read(rdh_ctx *c, rdh_counters *out) {
+    if (!c || !out) return RDH_ERR_ARGS;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Counters h;
+    HIP_TRY(c, hipMemcpy(&h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost));
+    out->closestRays = h.closestRays;
+    out->anyRays = h.anyRays;
+    out->nodeVisits = h.nodeVisits;
+    out->triTests = h.triTests;
+    out->closestHits = h.closestHits;
+    return RDH_OK;
+}
+
+int rdh_last_kernel_ms(rdh_ctx *c, float *ms) {
+    if (!c || !ms) return RDH_ERR_ARGS;
+    if (!c->timed) return fail(c, RDH_ERR_STATE, "no timed launch yet");
+    HIP_TRY(c, hipEventSynchronize(c->evStop));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->evStart, c->evStop));
+    return RDH_OK;
+}
+
+}  // extern "C"
