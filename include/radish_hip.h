@@ -97,7 +97,8 @@ typedef struct rdh_restir_params {
 int rdh_create(rdh_ctx **out, int device);
 void rdh_destroy(rdh_ctx *ctx);
 const char *rdh_last_error(const rdh_ctx *ctx);
-/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
+/* Launch on an existing hipStream_t (e.g. torch's current stream).  NULL selects HIP's default (null) stream; a
+ * context on which this is never called uses a private non-blocking stream. */
 int rdh_set_stream(rdh_ctx *ctx, void *hipStream);
 int rdh_synchronize(rdh_ctx *ctx);
 

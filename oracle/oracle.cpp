@@ -54,9 +54,9 @@ struct BinomialDistrib {  // src/sampler.h:66-69
     float prob;
     int failId;
 };
-struct LightLiSample {  // src/restir.h:95-99
+struct LightLiSample {  // src/restir.h:95-99; value-initialised by Reservoir (`SampleT sample = SampleT()`, :88)
     vec3 Li, wi;
-    float dist;
+    float dist = 0.f;
 };
 struct DirectReservoir {  // src/restir.h:10-92 (field order :88-92)
     LightLiSample sample;

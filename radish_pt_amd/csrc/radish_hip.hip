@@ -263,7 +263,7 @@ const char *rdh_last_error(const rdh_ctx *c) { return c ? c->err.c_str() : "null
 
 int rdh_set_stream(rdh_ctx *c, void *s) {
     if (!c) return RDH_ERR_ARGS;
-    c->stream = s ? static_cast<hipStream_t>(s) : c->ownStream;
+    c->stream = static_cast<hipStream_t>(s);  // NULL is HIP's default (null) stream, which is what torch uses by default
     return RDH_OK;
 }
 
