@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s and ms/frame of the hot path at BASELINE.json's headline configuration.
+
+Workload (config.workload): BASELINE config 2 — Cornell box stand-in (18 444 triangles; the reference's scene assets
+are absent), 1920x1080, 8 bounces, 1 spp per frame, `pathTrace` semantics.  A "step" is one frame: step s
+renders Sobol row `looper = s` with `iter = 0` (the reference app resets `iteration` every frame), into
+device-resident image buffers.
+
+N = 1:  one process, one GPU, frame layout.
+N > 1:  launched by torch.distributed.run, one rank per GPU.  The frame is cut into 64x64 tiles, tile t → rank t % N
+        (strong scaling: the frame is fixed, per-GPU work shrinks).  Each rank traces its tiles into packed tile
+        buffers; the finished tiles are exchanged with ONE RCCL all-gather per image per frame (all_gather_into_tensor
+        over xGMI) and re-assembled with rdh_untile — all inside the timed region.
+
+value = (closest-hit + any-hit rays actually traced in the K timed frames, all ranks) / (max-over-ranks wall time).
+Ray counts are exact device counters taken in an untimed pass over the same Sobol rows (the counters cost atomics,
+so the timed pass runs without them; the rays traced are identical).
+
+roofline: the dominant kernel is the traversal kernel (k_wf_trace in wavefront mode, the megakernel otherwise).
+`achieved` = algorithmic bytes ÷ the hipEvent-measured duration of its launches during the timed steps, with
+  B = 40·closestRays + 28·anyRays + 32·nodeVisits + 36·triTests + 64·closestHits          
+(ray in 24 B + hit record 16 B / occlusion flag 4 B; 32 B per box step; 36 B per triangle test; 64 B of normals, uvs and
+material id per found hit), against the 8.0 TB/s HBM3E peak.
+
+cpu_baseline: the oracle (CPU restatement, single thread) timed on every 3rd pixel of the same frame, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(c):
+    return (40 * c["closestRays"] + 28 * c["anyRays"] + 32 * c["nodeVisits"] + 36 * c["triTests"] + 64 * c["closestHits"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "wavefront"),
+                    choices=["mega", "wavefront", "wavefront_sort"])
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "teapots"])
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from radish_pt_amd import api, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    W, H, depth = args.width, args.height, args.depth
+    sd = scenes.cornell() if args.scene == "cornell" else scenes.teapots()
+    cam = scenes.cornell_camera(W, H) if args.scene == "cornell" else scenes.teapots_camera(W, H)
+    ctx = api.Context(dev.index)
+    ctx.upload_scene(sd)
+    ctx.set_camera(cam)
+    ctx.set_partition(rank, world, args.tile)
+    flags = {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
+             "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL}[args.mode]
+
+    if world == 1:
+        direct = torch.zeros(W * H, 3, device=dev)
+        indirect = torch.zeros(W * H, 3, device=dev)
+    else:
+        tpr = ctx.tiles_per_rank()
+        shard = tpr * args.tile * args.tile
+        direct = torch.zeros(shard, 3, device=dev)
+        indirect = torch.zeros(shard, 3, device=dev)
+        gath_d = torch.zeros(world * shard, 3, device=dev)
+        gath_i = torch.zeros(world * shard, 3, device=dev)
+        frame_d = torch.zeros(W * H, 3, device=dev)
+        frame_i = torch.zeros(W * H, 3, device=dev)
+
+    def step(s, f):
+        ctx.path_trace(direct, indirect, 0, s % api.SOBOL_SAMPLE_NUM, depth, f)
+        if world > 1:
+            dist.all_gather_into_tensor(gath_d, direct)
+            dist.all_gather_into_tensor(gath_i, indirect)
+            ctx.untile(gath_d, frame_d)
+            ctx.untile(gath_i, frame_i)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    K, Wm = args.steps, args.warmup
+    # untimed: warmup, then the exact work counters of the K frames that will be timed
+    for s in range(Wm):
+        step(s, flags)
+    torch.cuda.synchronize()
+    ctx.counters_reset()
+    for s in range(Wm, Wm + K):
+        ctx.path_trace(direct, indirect, 0, s % api.SOBOL_SAMPLE_NUM, depth, flags | api.RDH_PT_COUNT)
+    counters = ctx.counters()
+
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(Wm, Wm + K):
+        step(s, flags | api.RDH_PT_PROFILE)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    trace_ms, trace_launches = ctx.profile_read()
+
+    rays_local = counters["closestRays"] + counters["anyRays"]
+    stats = torch.tensor([elapsed, float(rays_local), float(algorithmic_bytes(counters)), trace_ms, float(trace_launches)],
+                         dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        rays_total = float(sm[1])
+    else:
+        rays_total = float(rays_local)
+
+    if rank == 0:
+        mrays = rays_total / elapsed / 1e6
+        launches = max(trace_launches, 1)
+        alg_bytes = algorithmic_bytes(counters)  # rank 0's launches
+        achieved = (alg_bytes / launches) / (trace_ms / launches * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                with open(pmc_path) as fh:
+                    traffic = json.load(fh).get(f"{args.scene}_{args.mode}_{W}x{H}_d{depth}_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} stand-in ({sd.num_prims} tris), {W}x{H}, {depth} bounces, 1 spp/frame, "
+                                   f"pathTrace ({args.mode}), tile-partitioned x{world}",
+                       "rays_per_frame": rays_total / K, "mode": args.mode, "parallelism": f"tile{args.tile}x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_wf_trace" if flags & api.RDH_PT_WAVEFRONT else "k_path_trace_mega",
+                         "launches": trace_launches, "avg_launch_ms": round(trace_ms / launches, 5),
+                         "algorithmic_bytes_per_launch": alg_bytes / launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle
+
+            o = pyoracle.OracleScene(sd)
+            ref_d = np.zeros((W * H, 3), np.float32)
+            ref_i = np.zeros((W * H, 3), np.float32)
+            stride = 3
+            if hasattr(os, "sched_setaffinity"):
+                try:
+                    os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+                except OSError:
+                    pass
+            tc = time.perf_counter()
+            o.path_trace(cam, ref_d, ref_i, 0, Wm, depth, pix=(0, W * H, stride))
+            cpu_s = time.perf_counter() - tc
+            st = o.stats()
+            cpu_rays = st["closestRays"] + st["anyRays"]
+            out["cpu_baseline"] = {
+                "value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                "sample": f"oracle pathTrace on every {stride}rd pixel of the same {W}x{H} depth-{depth} frame "
+                          f"(looper {Wm}): {cpu_rays} rays in {cpu_s:.1f} s",
+            }
+            # parity spot check on the timed configuration: the sampled pixels must equal the GPU frame bit for bit
+            ctx.path_trace(direct, indirect, 0, Wm, depth, flags)
+            idx = np.arange(0, W * H, stride)
+            g_d, g_i = direct.cpu().numpy(), indirect.cpu().numpy()
+            ok = (np.array_equal(g_d[idx].view(np.uint32), ref_d[idx].view(np.uint32))
+                  and np.array_equal(g_i[idx].view(np.uint32), ref_i[idx].view(np.uint32)))
+            out["parity_check"] = {"pixels": int(len(idx)), "bit_exact": bool(ok)}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,8 @@ typedef struct rdh_counters {
 #define RDH_PT_WAVEFRONT 1u    /* raygen / extend / shade / connect queues with wave64 ballot compaction    */
 #define RDH_PT_SORT_MATERIAL 2u/* wavefront only: bin hits by BSDF type before shading                      */
 #define RDH_PT_COUNT 4u        /* maintain rdh_counters (adds atomics; leave off when timing)               */
+#define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_wf_trace, or the megakernel)
+                                  with hipEvents on the context's stream; read with rdh_profile_read            */
 
 /* ReSTIR reuse mask = ReservoirReuse (src/common.h:41-48) */
 #define RDH_REUSE_TEMPORAL 1
@@ -148,6 +150,11 @@ int rdh_trace_occluded(rdh_ctx *ctx, const float *d_segments, int64_t n, int32_t
 
 int rdh_counters_reset(rdh_ctx *ctx);
 int rdh_counters_read(rdh_ctx *ctx, rdh_counters *out); /* blocking */
+
+/* Sum of the hipEvent-measured durations of the traversal-kernel launches made with RDH_PT_PROFILE since the last
+ * rdh_profile_reset, and how many launches that was (at most 8192 are recorded).  Both calls block. */
+int rdh_profile_reset(rdh_ctx *ctx);
+int rdh_profile_read(rdh_ctx *ctx, double *totalMs, int64_t *launches);
 
 /* Time of the most recent render call's kernels, measured with hipEvents on the context's stream (blocking);
  * the reference prints this figure from pathTrace (src/pathtrace.cu:364-374). */

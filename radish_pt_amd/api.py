@@ -25,7 +25,7 @@ from . import layouts as L
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libradish_hip.so")
 
-RDH_PT_MEGAKERNEL, RDH_PT_WAVEFRONT, RDH_PT_SORT_MATERIAL, RDH_PT_COUNT = 0, 1, 2, 4
+RDH_PT_MEGAKERNEL, RDH_PT_WAVEFRONT, RDH_PT_SORT_MATERIAL, RDH_PT_COUNT, RDH_PT_PROFILE = 0, 1, 2, 4, 8
 SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12
 
 # Every symbol include/radish_hip.h declares (tests check that the library exports all of them).
@@ -34,7 +34,7 @@ EXPORTS = [
     "rdh_scene_free", "rdh_set_camera", "rdh_set_partition", "rdh_tiles_per_rank", "rdh_untile", "rdh_path_trace",
     "rdh_path_trace_direct", "rdh_gbuffer_render", "rdh_restir_init", "rdh_restir_free", "rdh_restir_direct",
     "rdh_restir_read", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
-    "rdh_last_kernel_ms",
+    "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read",
 ]
 
 
@@ -109,6 +109,8 @@ def lib():
             "rdh_counters_reset": ([vp], i32),
             "rdh_counters_read": ([vp, C.POINTER(CountersC)], i32),
             "rdh_last_kernel_ms": ([vp, C.POINTER(C.c_float)], i32),
+            "rdh_profile_reset": ([vp], i32),
+            "rdh_profile_read": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)], i32),
         }
         for name, (args, res) in sig.items():
             fn = getattr(l, name)
@@ -235,6 +237,15 @@ class Context:
 
     def synchronize(self):
         self.check(lib().rdh_synchronize(self.h))
+
+    def profile_reset(self):
+        self.check(lib().rdh_profile_reset(self.h))
+
+    def profile_read(self):
+        """(total ms, launches) of the traversal-kernel launches made with RDH_PT_PROFILE since the last reset."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        self.check(lib().rdh_profile_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

@@ -48,6 +48,10 @@ struct rdh_ctx {
     long long restirPixels = 0;
     bool restirFirstFrame = true;
 
+    // per-launch timing of the dominant (traversal) kernel: ring of hipEvent pairs (RDH_PT_PROFILE)
+    std::vector<hipEvent_t> profEvents;
+    size_t profUsed = 0;
+
     // wavefront workspace
     WaveWorkspace wf{};
     long long wfCapacity = 0;
@@ -150,6 +154,25 @@ int requireReady(rdh_ctx *c) {
     return RDH_OK;
 }
 
+constexpr size_t kProfilePairs = 8192;
+
+// Returns the index of a fresh event pair (2*i, 2*i+1) or -1 when profiling is off / the ring is full.
+long profBegin(rdh_ctx *c, uint32_t flags) {
+    if (!(flags & RDH_PT_PROFILE) || c->profUsed >= kProfilePairs) return -1;
+    if (c->profEvents.size() < 2 * (c->profUsed + 1)) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        c->profEvents.push_back(a);
+        c->profEvents.push_back(b);
+    }
+    long i = (long)c->profUsed++;
+    hipEventRecord(c->profEvents[2 * i], c->stream);
+    return i;
+}
+void profEnd(rdh_ctx *c, long i) {
+    if (i >= 0) hipEventRecord(c->profEvents[2 * i + 1], c->stream);
+}
+
 // Persistent kernels: enough workgroups to fill every CU at full occupancy; surplus ones find the queues empty.
 constexpr unsigned kPersistentGrid = 256u * 8u;
 
@@ -191,10 +214,12 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     HIP_TRY(c, hipMemsetAsync(w.ctr, 0, sizeof(WaveCounters), c->stream));
     hipLaunchKernelGGL(k_wf_raygen, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, w, looper);
     for (int k = 0; k <= maxDepth; k++) {
+        long pe = profBegin(c, flags);
         if (count && sort) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
         else if (count) hipLaunchKernelGGL((k_wf_trace<true, false>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
         else if (sort) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
         else hipLaunchKernelGGL((k_wf_trace<false, false>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
+        profEnd(c, pe);
         hipLaunchKernelGGL(k_wf_shade, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k, maxDepth);
     }
     hipLaunchKernelGGL(k_wf_finish, dim3(gridFor(pm)), dim3(256), 0, c->stream, pm, w, iter, d_direct, d_indirect);
@@ -252,6 +277,7 @@ void rdh_destroy(rdh_ctx *c) {
     rdh_scene_free(c);
     rdh_restir_free(c);
     for (void *p : c->wfAllocs) hipFree(p);
+    for (hipEvent_t e : c->profEvents) hipEventDestroy(e);
     if (c->dCounters) hipFree(c->dCounters);
     if (c->evStart) hipEventDestroy(c->evStart);
     if (c->evStop) hipEventDestroy(c->evStop);
@@ -415,12 +441,14 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         return timeEnd(c, "pathTrace (wavefront)");
     }
     timeBegin(c);
+    long pe = profBegin(c, flags);
     if (count)
         hipLaunchKernelGGL(k_path_trace_mega<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
                            iter, maxDepth, d_direct, d_indirect);
     else
         hipLaunchKernelGGL(k_path_trace_mega<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
                            iter, maxDepth, d_direct, d_indirect);
+    profEnd(c, pe);
     return timeEnd(c, "pathTrace");
 }
 
@@ -598,6 +626,27 @@ int rdh_counters_read(rdh_ctx *c, rdh_counters *out) {
     out->nodeVisits = h.nodeVisits;
     out->triTests = h.triTests;
     out->closestHits = h.closestHits;
+    return RDH_OK;
+}
+
+int rdh_profile_reset(rdh_ctx *c) {
+    if (!c) return RDH_ERR_ARGS;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->profUsed = 0;
+    return RDH_OK;
+}
+
+int rdh_profile_read(rdh_ctx *c, double *totalMs, int64_t *launches) {
+    if (!c || !totalMs || !launches) return RDH_ERR_ARGS;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (size_t i = 0; i < c->profUsed; i++) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->profEvents[2 * i], c->profEvents[2 * i + 1]));
+        sum += ms;
+    }
+    *totalMs = sum;
+    *launches = (int64_t)c->profUsed;
     return RDH_OK;
 }
 
