@@ -1,4 +1,4 @@
-"""In-tree builds: libradish_host.so (g++), libradish_hip.so (hipcc, gfx950), oracle/liboracle.so (g++).
+"""In-tree builds of the product libraries: libradish_host.so (g++) and libradish_hip.so (hipcc, gfx950).
 
 Everything lands next to its sources so the `.so` files travel with the gpurun snapshot; nothing is installed.
 """
@@ -54,17 +54,8 @@ def build_hip(force=False):
     return out
 
 
-def build_oracle(force=False):
-    d = os.path.join(ROOT, "oracle")
-    if force:
-        subprocess.call(["make", "-C", d, "clean"])
-    _run(["make", "-C", d])
-    return os.path.join(d, "liboracle.so")
-
-
 def build_all(force=False):
     build_host(force)
-    build_oracle(force)
     build_hip(force)
 
 

@@ -15,8 +15,10 @@ def pytest_configure(config):
     # Build what is missing (seconds); the HIP library is only (re)built when hipcc is present.
     from radish_pt_amd import _build
 
+    import __graft_entry__
+
     _build.build_host()
-    _build.build_oracle()
+    __graft_entry__.build_oracle()
     if not os.path.exists(os.path.join(ROOT, "radish_pt_amd", "csrc", "libradish_hip.so")):
         _build.build_hip()
 
