@@ -59,11 +59,17 @@ RD_DEV void waveAppend(bool pred, int item, int *queue, int *count) {
     if (pred) queue[base + __popcll(mask & laneMaskLt())] = item;
 }
 
-// One packet of 64 consecutive items from a shared head.  Returns the first item index for this wave.
+// Work distribution for the persistent kernels.  Same-address returning atomics serialise chip-wide at ~12 ns each
+// (MI355X_MICROARCH.md "dequeue"/"fanin"), so (a) every wave's FIRST packet is static — wave g takes items
+// [g*kPacket, (g+1)*kPacket) — and the shared head only hands out what lies beyond gridWaves*kPacket, and (b) a pull
+// reserves kPacket = 128 items.  Heads are zeroed once per frame by the counters memset.
+constexpr int kPacket = 128;
+RD_DEV int globalWave() { return int(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
+RD_DEV int gridWaves() { return int(gridDim.x * (blockDim.x >> 6)); }
 RD_DEV int wavePull(int *head) {
     int base = 0;
-    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(head, 64);
-    return __shfl(base, 0, 64);
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(head, kPacket);
+    return __shfl(base, 0, 64) + gridWaves() * kPacket;
 }
 
 // ---- raygen ---------------------------------------------------------------------------------------------------
@@ -84,11 +90,22 @@ __global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelM
         w.accI[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         w.rng[p] = make_uint2(rng.scramble, (unsigned)rng.ptr);
     }
-    waveAppend(valid, p, w.rayq[0], &w.ctr->rayCount[0]);
+    // Bounce 0's queue is the identity over this launch's slots (-1 marks pixels outside the frame): no compaction,
+    // no atomic.
+    if (block < (unsigned)pm.numBlocks) w.rayq[0][p] = valid ? p : -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.ctr->rayCount[0] = pm.numBlocks * 64;
 }
 
 // ---- trace(k): shadow rays of bounce k (from shade(k-1)) + closest hits of bounce k ---------------------------
-template <bool COUNT, bool SORT>
+// Persistent waves with LANE REFILL: a wave reserves 64 consecutive work items per atomic and hands them to lanes
+// one by one as their previous ray finishes, so a wave never idles behind its longest ray (rays of one packet differ
+// several-fold in visit count after the first bounce).  Shadow (any-hit) and extension (closest-hit) rays run through
+// one walker; a lane's kind only decides how it terminates.
+#ifndef RD_REFILL_MIN
+#define RD_REFILL_MIN 16  // refill once at least this many lanes are idle
+#endif
+
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int k) {
     WaveCounters *c = w.ctr;
     const int nShadow = (k > 0) ? c->shadowCount[k - 1] : 0;
@@ -98,72 +115,210 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
     const int lane = int(threadIdx.x & 63u);
+    const int end = s.bvhSize;
+
+    // wave-uniform reservation of work items; the first one is static (see wavePull)
+    int resNext = globalWave() * kPacket, resEnd = resNext + kPacket;
+    bool exhausted = resNext >= total;
+    if (resEnd > total) resEnd = total;
+
+    // per-lane walker state
+    bool alive = false;
+    bool isShadow = false;
+    int p = -1;
+    RaySlab rs;
+    rs.o = rs.d = rs.inv = mk3(0.f);
+    rs.cls = 0;
+    const NodeRec *nodes = s.nodes[0];
+    int node = end, pending = -1;
+    float tmax = 0.f;
+    int hitPrim = -1;
+    v2 hitBary = mk2(0.f, 0.f);
+    bool occluded = false;
+
     for (;;) {
-        int base = wavePull(&c->traceHead[k]);
-        if (base >= total) break;
-        int item = base + lane;
-        bool isShadow = item < nShadow;
-        bool isRay = !isShadow && item < total;
-        int cls = -1;
-        int p = -1;
-        if (isShadow) {
-            p = w.shadowq[item];
-            float4 x = w.prevPos[p], y = w.sht[p];
-            nAny++;
-            bool occ = traceOccluded<COUNT>(s, mk3(x.x, x.y, x.z), mk3(y.x, y.y, y.z), ws);
-            float4 n = w.nee[p];
-            if (!occ && n.w >= 0.f) {
-                if (n.w == 0.f) {
-                    float4 a = w.accD[p];
-                    w.accD[p] = make_float4(a.x + n.x, a.y + n.y, a.z + n.z, 0.f);
-                } else {
-                    float4 a = w.accI[p];
-                    w.accI[p] = make_float4(a.x + n.x, a.y + n.y, a.z + n.z, 0.f);
+        // ---- hand new items to idle lanes ----
+        unsigned long long idle = __ballot(!alive);
+        int nIdle = __popcll(idle);
+        if (!exhausted && nIdle >= RD_REFILL_MIN) {
+            int myRank = __popcll(idle & laneMaskLt());
+            int taken = 0;  // items handed out so far in this refill (wave-uniform)
+            while (taken < nIdle && !exhausted) {
+                if (resNext == resEnd) {
+                    resNext = wavePull(&c->traceHead[k]);
+                    resEnd = resNext + kPacket;
+                    if (resNext >= total) {
+                        exhausted = true;
+                        break;
+                    }
+                    if (resEnd > total) resEnd = total;
                 }
-            }
-        } else if (isRay) {
-            p = rayq[item - nShadow];
-            float4 o = w.ro[p], d = w.rd[p];
-            Ray ray{mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z)};
-            nClosest++;
-            HitRec h = traceClosest<COUNT>(s, ray, ws);
-            w.hit[p] = make_int4(h.prim, __float_as_int(h.bary.x), __float_as_int(h.bary.y), __float_as_int(h.dist));
-            cls = 0;
-            if (h.prim != -1) {
-                nHits++;
-                if (SORT) {  // shading class = BSDF type; misses and emitters share class 0 (both terminate)
-                    int matId = __float_as_int(s.tris[h.prim].c.y);
-                    int type = __float_as_int(s.mats[matId].a.x);
-                    cls = (type == Lambertian) ? 1 : (type == MetallicWorkflow ? 2 : (type == Dielectric ? 3 : 0));
+                int avail = resEnd - resNext;
+                int give = (nIdle - taken) < avail ? (nIdle - taken) : avail;
+                if (!alive && myRank >= taken && myRank < taken + give) {
+                    int item = resNext + (myRank - taken);
+                    isShadow = item < nShadow;
+                    Ray ray;
+                    if (isShadow) {
+                        p = w.shadowq[item];
+                        float4 x4 = w.prevPos[p], y4 = w.sht[p];
+                        v3 x = mk3(x4.x, x4.y, x4.z), y = mk3(y4.x, y4.y, y4.z);
+                        v3 dir = y - x;  // DevScene::testOcclusion's ray set-up (scene.h:304-311)
+                        float dist = length(dir);
+                        dir = dir / dist;
+                        tmax = dist - 1e-4f;
+                        ray = makeOffsetedRay(x, dir);
+                        nAny++;
+                    } else {
+                        p = rayq[item - nShadow];
+                        if (p >= 0) {
+                            float4 o = w.ro[p], d = w.rd[p];
+                            ray = Ray{mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z)};
+                            tmax = 3.402823466e+38f;
+                            nClosest++;
+                        } else {
+                            ray = Ray{mk3(0.f), mk3(0.f, 0.f, 1.f)};  // off-frame slot of bounce 0: nothing to trace
+                        }
+                    }
+                    if (p >= 0) {
+                        rs = makeRaySlab(ray);
+                        nodes = s.nodes[getMTBVHId(-ray.d)];
+                        node = 0;
+                        pending = -1;
+                        hitPrim = -1;
+                        occluded = false;
+                        alive = node != end;
+                    }
                 }
+                resNext += give;
+                taken += give;
             }
         }
-        if (SORT) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) waveAppend(cls == q, p, w.hitq[q], &c->hitCount[k][q]);
-        } else {
-            waveAppend(cls == 0, p, w.hitq[0], &c->hitCount[k][0]);
+        unsigned long long am = __ballot(alive);
+        if (am == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        const int minAlive = exhausted ? 1 : (64 - RD_REFILL_MIN + 1);
+
+        // ---- box steps until enough lanes are parked on a leaf or enough lanes have finished ----
+        for (;;) {
+            bool walking = alive && pending < 0;
+            unsigned long long wm = __ballot(walking);
+            if (wm == 0ull) break;
+            unsigned long long pm = __ballot(alive && pending >= 0);
+            int nPark = __popcll(pm), nWalk = __popcll(wm);
+            if (pm != 0ull && nPark * RD_LEAF_DEN >= (nWalk + nPark) * RD_LEAF_NUM) break;
+            if (nWalk + nPark < minAlive) break;
+            if (walking) {
+                float4 lo = nodes[node].lo_prim;
+                float4 hi = nodes[node].hi_next;
+                float boundDist;
+                if (COUNT) ws.nodes++;
+                bool boundHit = boxTest(lo, hi, rs, boundDist);
+                if (boundHit && boundDist < tmax) {
+                    pending = __float_as_int(lo.w);
+                    node++;
+                } else {
+                    node = __float_as_int(hi.w);
+                }
+                alive = (node != end) || pending >= 0;
+            }
+        }
+        // ---- triangle tests of the parked lanes ----
+        if (alive && pending >= 0) {
+            TriVerts t = loadTri(s.tris, pending);
+            float dist;
+            v2 bary;
+            if (COUNT) ws.tris++;
+            bool hit = intersectTriangle(rs, t.a, t.b, t.c, bary, dist);
+            if (hit && dist < tmax) {
+                if (isShadow) {
+                    occluded = true;
+                    node = end;
+                } else {
+                    hitPrim = pending;
+                    tmax = dist;
+                    hitBary = bary;
+                }
+            }
+            pending = -1;
+            alive = node != end;
+        }
+        // ---- retire finished lanes ----
+        if (!alive && p >= 0) {
+            if (isShadow) {
+                float4 n = w.nee[p];
+                if (!occluded && n.w >= 0.f) {  // the addition sampleDirectLight's caller makes (pathtrace.cu:201-207)
+                    if (n.w == 0.f) {
+                        float4 a = w.accD[p];
+                        w.accD[p] = make_float4(a.x + n.x, a.y + n.y, a.z + n.z, 0.f);
+                    } else {
+                        float4 a = w.accI[p];
+                        w.accI[p] = make_float4(a.x + n.x, a.y + n.y, a.z + n.z, 0.f);
+                    }
+                }
+            } else {
+                bool hit = hitPrim != -1;
+                if (hit) nHits++;
+                w.hit[p] = make_int4(hitPrim, __float_as_int(hit ? hitBary.x : 0.f), __float_as_int(hit ? hitBary.y : 0.f),
+                                     __float_as_int(tmax));
+            }
+            p = -1;
         }
     }
     if (COUNT) flushCounters(s.counters, nClosest, nAny, nHits, ws);
 }
 
+// ---- classify(k) (material sort only): bin bounce k's hit records by BSDF type ------------------------------------
+// Four queues: 0 = terminal (miss / emitter / unknown), 1 = Lambertian, 2 = metallic workflow, 3 = dielectric.
+// One ballot + one atomic per wave per non-empty class per 64 records.
+__global__ __launch_bounds__(256) void k_wf_classify(DScene s, WaveWorkspace w, int k) {
+    WaveCounters *c = w.ctr;
+    const int n = c->rayCount[k];
+    const int *rayq = w.rayq[k & 1];
+    const int stride = gridWaves() * 64;
+    for (int i = globalWave() * 64 + int(threadIdx.x & 63u); i - int(threadIdx.x & 63u) < n; i += stride) {
+        int p = (i < n) ? rayq[i] : -1;
+        int cls = -1;
+        if (p >= 0) {
+            int prim = w.hit[p].x;
+            cls = 0;
+            if (prim != -1) {
+                int matId = __float_as_int(s.tris[prim].c.y);
+                int type = __float_as_int(s.mats[matId].a.x);
+                cls = (type == Lambertian) ? 1 : (type == MetallicWorkflow ? 2 : (type == Dielectric ? 3 : 0));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) waveAppend(cls == q, p, w.hitq[q], &c->hitCount[k][q]);
+    }
+}
+
 // ---- shade(k): hit k → terminate or run bounce body k+1 ----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int k, int maxDepth) {
+// sorted != 0: drain the four class queues one after the other; else walk bounce k's ray queue as it is.
+__global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int k, int maxDepth, int sorted) {
     WaveCounters *c = w.ctr;
     const int lane = int(threadIdx.x & 63u);
-    for (int q = 0; q < 4; q++) {
-        const int n = c->hitCount[k][q];
-        const int *hitq = w.hitq[q];
-        for (;;) {
-            int base = wavePull(&c->shadeHead[k][q]);
-            if (base >= n) break;
-            int item = base + lane;
+    for (int q = 0; q < (sorted ? 4 : 1); q++) {
+        const int n = sorted ? c->hitCount[k][q] : c->rayCount[k];
+        const int *hitq = sorted ? w.hitq[q] : w.rayq[k & 1];
+        for (int base = globalWave() * kPacket, sub = 0;;) {
+            if (sub == kPacket) {
+                base = wavePull(&c->shadeHead[k][q]);
+                sub = 0;
+            }
+            if (base + sub >= n) break;
+            int item = base + sub + lane;
+            sub += 64;
             bool active = item < n;
             bool emitShadow = false, emitRay = false;
             int p = -1;
             if (active) {
                 p = hitq[item];
+                active = p >= 0;
+            }
+            if (active) {
                 int4 h = w.hit[p];
                 float4 rdw = w.rd[p];
                 v3 rayDir = mk3(rdw.x, rdw.y, rdw.z);

@@ -30,7 +30,8 @@ RD_DEV int getMTBVHId(v3 dir) {  // scene.h:114-129 (called with -ray.direction)
 // Per-ray constants of AABB::intersect.
 struct RaySlab {
     v3 o, d, inv;
-    int cls;  // 0: no special case applies; 1/2/3: |d.x|/|d.y|/|d.z| > 1-Eps; 4: some |d.k| < Eps
+    int cls;  // 0: no special case applies; 1/2/3: |d.x|/|d.y|/|d.z| > 1-Eps; 4: some |d.k| < Eps;
+              // 5: non-finite or astronomically far ray (literal path, so NaN/inf propagate as in the reference)
 };
 RD_DEV RaySlab makeRaySlab(const Ray &r) {
     const float Eps = 1e-6f;
@@ -44,6 +45,11 @@ RD_DEV RaySlab makeRaySlab(const Ray &r) {
     else if (az > 1.f - Eps) s.cls = 3;
     else if (ax < Eps || ay < Eps || az < Eps) s.cls = 4;
     else s.cls = 0;
+    // `!(x < bound)` is also true for NaN
+    const float Far = 1e30f;
+    if (!(fabs_(r.o.x) < Far) || !(fabs_(r.o.y) < Far) || !(fabs_(r.o.z) < Far) || !(ax <= 1.f) || !(ay <= 1.f) ||
+        !(az <= 1.f))
+        s.cls = (s.cls == 0) ? 5 : s.cls;
     return s;
 }
 
@@ -62,7 +68,7 @@ RD_DEV bool distMaxMin(float a1, float a2, float b1, float b2, float &tMin) {  /
 // AABB::intersect (bvh.h:91-155)
 RD_DEV bool aabbIntersect(v3 pMin, v3 pMax, const RaySlab &r, float &tMin) {
     const float Eps = 1e-6f;
-    if (r.cls != 0 && r.cls != 4) {
+    if (r.cls >= 1 && r.cls <= 3) {
         if (r.cls == 1) {
             if (between(r.o.y, pMin.y, pMax.y) && between(r.o.z, pMin.z, pMax.z)) {
                 float t1 = (pMin.x - r.o.x) * r.inv.x, t2 = (pMax.x - r.o.x) * r.inv.x;
@@ -102,28 +108,29 @@ RD_DEV bool aabbIntersect(v3 pMin, v3 pMax, const RaySlab &r, float &tMin) {
     return false;
 }
 
-// intersectTriangle (intersections.h:20-68)
+// intersectTriangle (intersections.h:20-68), straight-line: every lane that tests computes the whole expression and
+// the early-outs become one conjunction.  Same operations in the same order, so the accepted hits and their
+// {bary, dist} bits are those of the early-out form (a rejected candidate's leftovers are never read).
 RD_DEV bool intersectTriangle(const RaySlab &ray, v3 v0, v3 v1, v3 vc, v2 &bary, float &dist) {
     v3 e01 = v1 - v0;
     v3 e02 = vc - v0;
     v3 pvec = cross(ray.d, e02);
     float det = dot(e01, pvec);
-    if (fabs_(det) < 1.1920928955078125e-7f) return false;  // FLT_EPSILON
+    bool ok = !(fabs_(det) < 1.1920928955078125e-7f);  // FLT_EPSILON
     v3 v0ToOri = ray.o - v0;
-    if (det < 0.f) {
-        det = -det;
-        v0ToOri = -v0ToOri;
-    }
-    bary.x = dot(v0ToOri, pvec);
-    if (bary.x < 0.f || bary.x > det) return false;
+    bool neg = det < 0.f;
+    det = neg ? -det : det;
+    v0ToOri = neg ? -v0ToOri : v0ToOri;
+    float bx = dot(v0ToOri, pvec);
+    ok = ok && !(bx < 0.f || bx > det);
     v3 qvec = cross(v0ToOri, e01);
-    bary.y = dot(ray.d, qvec);
-    if (bary.y < 0.f || bary.x + bary.y > det) return false;
+    float by = dot(ray.d, qvec);
+    ok = ok && !(by < 0.f || bx + by > det);
     float invDet = 1.f / det;
-    bary.x = bary.x * invDet;
-    bary.y = bary.y * invDet;
+    bary.x = bx * invDet;
+    bary.y = by * invDet;
     dist = dot(e02, qvec) * invDet;
-    return dist > 0.f;
+    return ok && dist > 0.f;
 }
 
 struct TriVerts {
@@ -151,42 +158,106 @@ struct HitRec {
     float dist;
 };
 
-// DevScene::intersect (scene.h:262-301), geometry part.  `prim` = NullPrimitive (-1) on a miss.
-template <bool COUNT>
-RD_DEV HitRec traceClosest(const DScene &s, const Ray &ray, WalkStats &ws) {
+// Slab test for the common ray class (cls 0: finite ray, no |d.k| > 1-Eps, no |d.k| < Eps): the last branch of
+// AABB::intersect (bvh.h:125-154) with nothing else reachable.  All t values are finite here (|inv| <= 1e6 and
+// rdh_scene_upload bounds the scene), so v_min/v_max equal glm::min/max and C fminf/fmaxf up to the sign of a zero,
+// which no comparison below can see.
+RD_DEV bool aabbFast(float4 lo, float4 hi, const RaySlab &r, float &tMin) {
+    float t1x = (lo.x - r.o.x) * r.inv.x, t1y = (lo.y - r.o.y) * r.inv.y, t1z = (lo.z - r.o.z) * r.inv.z;
+    float t2x = (hi.x - r.o.x) * r.inv.x, t2y = (hi.y - r.o.y) * r.inv.y, t2z = (hi.z - r.o.z) * r.inv.z;
+    float nx = __builtin_fminf(t1x, t2x), ny = __builtin_fminf(t1y, t2y), nz = __builtin_fminf(t1z, t2z);
+    float fx = __builtin_fmaxf(t1x, t2x), fy = __builtin_fmaxf(t1y, t2y), fz = __builtin_fmaxf(t1z, t2z);
+    float dx = fx - nx, dy = fy - ny, dz = fz - nz;
+    float yz = fz - ny, zx = fx - nz, xy = fy - nx;
+    bool overlap = (dy + dz > yz) && (dz + dx > zx) && (dx + dy > xy);
+    tMin = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+    float tMax = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    return overlap && tMax >= 0.f && tMax >= tMin;
+}
+
+RD_DEV bool boxTest(float4 lo, float4 hi, const RaySlab &rs, float &t) {
+    if (rs.cls == 0) return aabbFast(lo, hi, rs, t);
+    return aabbIntersect(mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), rs, t);
+}
+
+// How many of the still-running lanes must be parked on a leaf before the wave leaves the box loop to run the
+// triangle tests together: parked * kLeafDen >= running * kLeafNum.
+#ifndef RD_LEAF_NUM
+#define RD_LEAF_NUM 1
+#endif
+#ifndef RD_LEAF_DEN
+#define RD_LEAF_DEN 4
+#endif
+
+// One threaded-BVH walk per lane (DevScene::intersect, scene.h:262-301, and DevScene::testOcclusion's loop,
+// :316-333).  Each lane performs exactly the reference's sequence — box test, on a leaf hit the triangle test, strict
+// `<` updates, node++ / nextNodeIfMiss — but the wave runs it "while-while": lanes step through boxes until enough of
+// them are parked on a leaf, then the parked lanes test their triangles together.  Only ~3 % of visits reach a
+// triangle, so testing as soon as ONE lane needs it (the if-if form) makes every step pay for a triangle test.
+// ANY = true: any-hit with a fixed distance bound; returns true on the first accepted triangle.
+template <bool COUNT, bool ANY>
+RD_DEV bool walkRay(const DScene &s, const Ray &ray, float tLimit, HitRec &h, WalkStats &ws) {
     RaySlab rs = makeRaySlab(ray);
     const NodeRec *nodes = s.nodes[getMTBVHId(-ray.d)];
-    HitRec h;
     h.prim = -1;
     h.bary = mk2(0.f, 0.f);
-    h.dist = 3.402823466e+38f;  // FLT_MAX
+    h.dist = tLimit;
     int node = 0;
     const int end = s.bvhSize;
-    while (node != end) {
-        float4 lo = nodes[node].lo_prim;
-        float4 hi = nodes[node].hi_next;
-        float boundDist;
-        if (COUNT) ws.nodes++;
-        bool boundHit = aabbIntersect(mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), rs, boundDist);
-        if (boundHit && boundDist < h.dist) {
-            int primId = __float_as_int(lo.w);
-            if (primId != -1) {
-                TriVerts t = loadTri(s.tris, primId);
-                float dist;
-                v2 bary;
-                if (COUNT) ws.tris++;
-                bool hit = intersectTriangle(rs, t.a, t.b, t.c, bary, dist);
-                if (hit && dist < h.dist) {
-                    h.prim = primId;
+    int pending = -1;
+    bool alive = node != end;
+    bool found = false;
+    for (;;) {
+        for (;;) {
+            bool walking = alive && pending < 0;
+            unsigned long long wm = __ballot(walking);
+            if (wm == 0ull) break;
+            unsigned long long pm = __ballot(alive && pending >= 0);
+            if (__popcll(pm) * RD_LEAF_DEN >= (__popcll(wm) + __popcll(pm)) * RD_LEAF_NUM && pm != 0ull) break;
+            if (walking) {
+                float4 lo = nodes[node].lo_prim;
+                float4 hi = nodes[node].hi_next;
+                float boundDist;
+                if (COUNT) ws.nodes++;
+                bool boundHit = boxTest(lo, hi, rs, boundDist);
+                if (boundHit && boundDist < h.dist) {
+                    pending = __float_as_int(lo.w);  // -1 for an inner node
+                    node++;
+                } else {
+                    node = __float_as_int(hi.w);
+                }
+                alive = (node != end) || pending >= 0;
+            }
+        }
+        if (__ballot(alive) == 0ull) break;
+        if (alive && pending >= 0) {
+            TriVerts t = loadTri(s.tris, pending);
+            float dist;
+            v2 bary;
+            if (COUNT) ws.tris++;
+            bool hit = intersectTriangle(rs, t.a, t.b, t.c, bary, dist);
+            if (hit && dist < h.dist) {
+                if (ANY) {
+                    found = true;
+                    node = end;
+                } else {
+                    h.prim = pending;
                     h.dist = dist;
                     h.bary = bary;
                 }
             }
-            node++;
-        } else {
-            node = __float_as_int(hi.w);
+            pending = -1;
+            alive = node != end;
         }
     }
+    return ANY ? found : (h.prim != -1);
+}
+
+// DevScene::intersect (scene.h:262-301), geometry part.  `prim` = NullPrimitive (-1) on a miss.
+template <bool COUNT>
+RD_DEV HitRec traceClosest(const DScene &s, const Ray &ray, WalkStats &ws) {
+    HitRec h;
+    walkRay<COUNT, false>(s, ray, 3.402823466e+38f /* FLT_MAX */, h, ws);
     return h;
 }
 
@@ -199,32 +270,8 @@ RD_DEV bool traceOccluded(const DScene &s, v3 x, v3 y, WalkStats &ws) {
     dir = dir / dist;
     dist -= eps;
     Ray ray = makeOffsetedRay(x, dir);
-    RaySlab rs = makeRaySlab(ray);
-    const NodeRec *nodes = s.nodes[getMTBVHId(-ray.d)];
-    int node = 0;
-    const int end = s.bvhSize;
-    while (node != end) {
-        float4 lo = nodes[node].lo_prim;
-        float4 hi = nodes[node].hi_next;
-        float boundDist;
-        if (COUNT) ws.nodes++;
-        bool boundHit = aabbIntersect(mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), rs, boundDist);
-        if (boundHit && boundDist < dist) {
-            int primId = __float_as_int(lo.w);
-            if (primId != -1) {
-                TriVerts t = loadTri(s.tris, primId);
-                float d;
-                v2 bary;
-                if (COUNT) ws.tris++;
-                bool hit = intersectTriangle(rs, t.a, t.b, t.c, bary, d);
-                if (hit && d < dist) return true;
-            }
-            node++;
-        } else {
-            node = __float_as_int(hi.w);
-        }
-    }
-    return false;
+    HitRec h;
+    return walkRay<COUNT, true>(s, ray, dist, h, ws);
 }
 
 // Wave-level reduction of the per-lane walk statistics, then one atomic per counter per wave.

@@ -215,12 +215,11 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     hipLaunchKernelGGL(k_wf_raygen, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, w, looper);
     for (int k = 0; k <= maxDepth; k++) {
         long pe = profBegin(c, flags);
-        if (count && sort) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
-        else if (count) hipLaunchKernelGGL((k_wf_trace<true, false>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
-        else if (sort) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
-        else hipLaunchKernelGGL((k_wf_trace<false, false>), dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
+        if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
+        else hipLaunchKernelGGL(k_wf_trace<false>, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
         profEnd(c, pe);
-        hipLaunchKernelGGL(k_wf_shade, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k, maxDepth);
+        if (sort) hipLaunchKernelGGL(k_wf_classify, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
+        hipLaunchKernelGGL(k_wf_shade, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k, maxDepth, sort ? 1 : 0);
     }
     hipLaunchKernelGGL(k_wf_finish, dim3(gridFor(pm)), dim3(256), 0, c->stream, pm, w, iter, d_direct, d_indirect);
     return RDH_OK;
@@ -354,6 +353,8 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
             if (box < 0 || box >= S || next < 0 || next > S || prim < -1 || prim >= N || next <= i)
                 return fail(c, RDH_ERR_ARGS, "bvhNodes[%d][%d] = {%d,%d,%d} is not a valid threaded node", k, i, prim, box, next);
             const float *b = d->boundingBoxes + 6 * (size_t)box;
+            for (int q = 0; q < 6; q++)  // aabbFast (device/traverse.h) assumes finite, moderately sized coordinates
+                if (!(std::fabs(b[q]) < 1e30f)) return fail(c, RDH_ERR_ARGS, "boundingBoxes[%d] is not finite / exceeds 1e30", box);
             nodes[i].lo_prim = make_float4(b[0], b[1], b[2], asFloat(prim));
             nodes[i].hi_next = make_float4(b[3], b[4], b[5], asFloat(next));
         }
