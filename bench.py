@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "wavefront"),
-                    choices=["mega", "wavefront", "wavefront_sort"])
+                    choices=["mega", "wavefront", "wavefront_sort", "persistent"])
     ap.add_argument("--scene", default="cornell", choices=["cornell", "teapots"])
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,7 +88,8 @@ def main():
     ctx.set_camera(cam)
     ctx.set_partition(rank, world, args.tile)
     flags = {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
-             "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL}[args.mode]
+             "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,
+             "persistent": api.RDH_PT_PERSISTENT}[args.mode]
 
     if world == 1:
         direct = torch.zeros(W * H, 3, device=dev)
@@ -172,7 +173,8 @@ def main():
                        "rays_per_frame": rays_total / K, "mode": args.mode, "parallelism": f"tile{args.tile}x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_wf_trace" if flags & api.RDH_PT_WAVEFRONT else "k_path_trace_mega",
+                         "kernel": ("k_wf_trace" if flags & api.RDH_PT_WAVEFRONT else
+                                    "k_pt_persistent" if flags & api.RDH_PT_PERSISTENT else "k_path_trace_mega"),
                          "launches": trace_launches, "avg_launch_ms": round(trace_ms / launches, 5),
                          "algorithmic_bytes_per_launch": alg_bytes / launches},
         }

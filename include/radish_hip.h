@@ -80,6 +80,7 @@ typedef struct rdh_counters {
 #define RDH_PT_WAVEFRONT 1u    /* raygen / extend / shade / connect queues with wave64 ballot compaction    */
 #define RDH_PT_SORT_MATERIAL 2u/* wavefront only: bin hits by BSDF type before shading                      */
 #define RDH_PT_COUNT 4u        /* maintain rdh_counters (adds atomics; leave off when timing)               */
+#define RDH_PT_PERSISTENT 16u  /* one persistent launch: per-lane state machine with lane refill (kernels_persist.h) */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read            */
 

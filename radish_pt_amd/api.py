@@ -26,6 +26,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libradish_hip.so")
 
 RDH_PT_MEGAKERNEL, RDH_PT_WAVEFRONT, RDH_PT_SORT_MATERIAL, RDH_PT_COUNT, RDH_PT_PROFILE = 0, 1, 2, 4, 8
+RDH_PT_PERSISTENT = 16
 SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12
 
 # Every symbol include/radish_hip.h declares (tests check that the library exports all of them).

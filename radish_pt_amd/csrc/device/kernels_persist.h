@@ -1,0 +1,329 @@
+// radish_pt_amd/csrc/device/kernels_persist.h — pathTrace as ONE persistent launch: a per-lane state machine with
+// lane refill ("wavefront in registers").
+//
+// Why: node visits per ray are heavy-tailed on the reference's threaded BVH (Cornell stand-in: median 1, mean 34,
+// p99 ≈ 950, max ≈ 2 800 dependent steps).  A kernel boundary per bounce (kernels_wave.h) makes every bounce wait for
+// its longest ray (≈0.4–0.6 ms each, nine times per frame), and a one-lane-per-pixel megakernel makes every wave wait
+// for its longest path.  Here a lane that finishes a ray shades it and carries on; a lane whose path ends takes the
+// next pixel; the frame's critical path is the longest single PATH, and lanes stay busy until the frame runs dry.
+//
+// Every lane executes exactly singleKernelPT's sequence for its pixel (/root/reference/src/pathtrace.cu:149-291):
+// primary ray → [NEE sample → shadow ray → BSDF sample → extension ray]* with the same RNG draws and the same order of
+// additions, so the result is bit-identical to the megakernel and to the queue pipeline.  Wave-level scheduling only
+// decides WHEN a lane's next step runs:
+//   box steps   while enough lanes are walking,
+//   leaf tests  when >= RD_LEAF_NUM/RD_LEAF_DEN of the tracing lanes are parked on a leaf,
+//   shading     when >= RD_SHADE_MIN lanes wait for it (or nothing else can run),
+//   raygen      when >= RD_REFILL_MIN lanes are idle and pixels remain.
+// Path state that is live only across phases (throughput, accumulators, the pending extension ray, …) sits in LDS,
+// 84 B per lane, so the traversal loop runs on the walker's registers alone.
+#pragma once
+#include "kernels_pt.h"
+
+namespace rd {
+
+#ifndef RD_SHADE_MIN
+#define RD_SHADE_MIN 16
+#endif
+#ifndef RD_PIX_REFILL_MIN
+#define RD_PIX_REFILL_MIN 16
+#endif
+
+struct PersistCounters {
+    int blockHead;  // next 8x8 pixel block beyond the static first round (see k_pt_persistent)
+};
+
+constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
+                                                       float *__restrict__ directIllum, float *__restrict__ indirectIllum,
+                                                       PersistCounters *pc) {
+    // ---- LDS-resident path state (SoA: lane-consecutive, conflict-free) ----
+    __shared__ float sThr[3][256], sAccD[3][256], sAccI[3][256], sCur[3][256];
+    __shared__ float sExtO[3][256], sExtD[3][256], sExtPdf[256], sNee[4][256];
+    __shared__ int sFlags[256];  // bit0: extension ray pending, bit1: that sample was specular
+    const int t = int(threadIdx.x);
+    const int lane = t & 63;
+    const int end = s.bvhSize;
+    const int numBlocks = pm.numBlocks;
+    // xcdSwizzle is a bijection on the group range padded to a multiple of 8: walk the padded range, skip the padding
+    const int paddedBlocks = int((((unsigned)(numBlocks + 3) / 4u + 7u) / 8u) * 8u * 4u);
+
+    WalkStats ws{0, 0};
+    unsigned nClosest = 0, nAny = 0, nHits = 0;
+
+    // wave-uniform pixel reservation: one 8x8 block at a time; the first is static (wave g takes block g)
+    int curBlock = int(blockIdx.x * 4u + (threadIdx.x >> 6));
+    int slotNext = 0;  // next unassigned pixel slot (0..63) of curBlock
+    const int gridWavesN = int(gridDim.x * 4u);
+    bool exhausted = curBlock >= paddedBlocks;
+
+    // per-lane registers
+    int state = PS_IDLE;
+    int outIdx = 0;
+    int k = 0;  // index of the hit the current extension ray leads to (0 = primary)
+    uint32_t rngScramble = 0;
+    int rngPtr = 0;
+    RaySlab rs;
+    rs.o = rs.d = rs.inv = mk3(0.f);
+    rs.cls = 0;
+    const NodeRec *nodes = s.nodes[0];
+    int node = end, pending = -1;
+    float tmax = 0.f;
+    int hitPrim = -1;
+    v2 hitBary = mk2(0.f, 0.f);
+    bool isShadow = false, occluded = false;
+
+    auto startTrace = [&](const Ray &ray, float limit, bool shadow) {
+        rs = makeRaySlab(ray);
+        nodes = s.nodes[getMTBVHId(-ray.d)];
+        node = 0;
+        pending = -1;
+        hitPrim = -1;
+        occluded = false;
+        tmax = limit;
+        isShadow = shadow;
+        state = PS_TRACE;
+    };
+    auto startShadow = [&](v3 x, v3 y) {  // DevScene::testOcclusion's ray set-up (scene.h:304-311)
+        v3 dir = y - x;
+        float dist = length(dir);
+        dir = dir / dist;
+        nAny++;
+        startTrace(makeOffsetedRay(x, dir), dist - 1e-4f, true);
+    };
+    auto finishPixel = [&]() {  // pathtrace.cu:279-290
+        v3 direct = mk3(sAccD[0][t], sAccD[1][t], sAccD[2][t]);
+        v3 indirect = mk3(sAccI[0][t], sAccI[1][t], sAccI[2][t]);
+        if (hasNanOrInf(direct)) direct = mk3(0.f);
+        if (hasNanOrInf(indirect)) indirect = mk3(0.f);
+        direct = HDRToLDR(direct);
+        indirect = HDRToLDR(indirect);
+        storeRunningMean(directIllum, outIdx, direct, iter);
+        storeRunningMean(indirectIllum, outIdx, indirect, iter);
+        state = PS_IDLE;
+    };
+    auto startExtensionOrFinish = [&]() {
+        if (sFlags[t] & 1) {
+            Ray ray{mk3(sExtO[0][t], sExtO[1][t], sExtO[2][t]), mk3(sExtD[0][t], sExtD[1][t], sExtD[2][t])};
+            nClosest++;
+            startTrace(ray, 3.402823466e+38f, false);
+        } else {
+            finishPixel();
+        }
+    };
+
+    for (;;) {
+        // ---------------- raygen for idle lanes ----------------
+        unsigned long long idleM = __ballot(state == PS_IDLE);
+        int nIdle = __popcll(idleM);
+        if (!exhausted && nIdle >= RD_PIX_REFILL_MIN) {
+            int myRank = __popcll(idleM & laneMaskLt());
+            int taken = 0;
+            while (taken < nIdle && !exhausted) {
+                if (slotNext == 64) {
+                    int b = 0;
+                    if (lane == 0) b = atomicAdd(&pc->blockHead, 1);
+                    curBlock = __shfl(b, 0, 64) + gridWavesN;
+                    slotNext = 0;
+                    if (curBlock >= paddedBlocks) {
+                        exhausted = true;
+                        break;
+                    }
+                }
+                int avail = 64 - slotNext;
+                int give = (nIdle - taken) < avail ? (nIdle - taken) : avail;
+                if (state == PS_IDLE && myRank >= taken && myRank < taken + give) {
+                    // XCD-aware block order as in the one-shot kernels: workgroup-sized groups of 4 blocks
+                    unsigned wgLogical;
+                    bool ok = xcdSwizzle((unsigned)curBlock >> 2, (unsigned)(numBlocks + 3) >> 2, wgLogical);
+                    Pix px = mapPixel(pm, ok ? wgLogical * 4u + ((unsigned)curBlock & 3u) : 0xffffffffu / 64u,
+                                      (unsigned)(slotNext + (myRank - taken)));
+                    if (px.valid && ok) {
+                        outIdx = px.out;
+                        Sampler rng = makeSeededRandomEngine(looper, px.index, 0, s.sobol);
+                        Ray ray = cameraSample(cam, px.x, px.y, sample4D(rng));
+                        rngScramble = rng.scramble;
+                        rngPtr = rng.ptr;
+                        sAccD[0][t] = sAccD[1][t] = sAccD[2][t] = 0.f;
+                        sAccI[0][t] = sAccI[1][t] = sAccI[2][t] = 0.f;
+                        k = 0;
+                        nClosest++;
+                        startTrace(ray, 3.402823466e+38f, false);
+                    }
+                }
+                slotNext += give;
+                taken += give;
+            }
+        }
+        if (__ballot(state != PS_IDLE) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---------------- box steps ----------------
+        for (;;) {
+            bool tracing = state == PS_TRACE;
+            bool walking = tracing && pending < 0 && node != end;
+            unsigned long long wm = __ballot(walking);
+            if (wm == 0ull) break;
+            unsigned long long pmk = __ballot(tracing && pending >= 0);
+            int nWalk = __popcll(wm), nPark = __popcll(pmk);
+            if (pmk != 0ull && nPark * RD_LEAF_DEN >= (nWalk + nPark) * RD_LEAF_NUM) break;
+            unsigned long long fin = __ballot(tracing && pending < 0 && node == end);  // traces waiting to retire
+            unsigned long long shd = __ballot(state == PS_SHADE);
+            int nIdleNow = 64 - nWalk - nPark - __popcll(fin) - __popcll(shd);
+            if (__popcll(fin) + __popcll(shd) >= RD_SHADE_MIN) break;
+            if (!exhausted && nIdleNow >= RD_PIX_REFILL_MIN) break;
+            if (walking) {
+                float4 lo = nodes[node].lo_prim;
+                float4 hi = nodes[node].hi_next;
+                float boundDist;
+                if (COUNT) ws.nodes++;
+                bool boundHit = boxTest(lo, hi, rs, boundDist);
+                if (boundHit && boundDist < tmax) {
+                    pending = __float_as_int(lo.w);
+                    node++;
+                } else {
+                    node = __float_as_int(hi.w);
+                }
+            }
+        }
+        // ---------------- leaf tests of parked lanes ----------------
+        if (state == PS_TRACE && pending >= 0) {
+            TriVerts tv = loadTri(s.tris, pending);
+            float dist;
+            v2 bary;
+            if (COUNT) ws.tris++;
+            bool hit = intersectTriangle(rs, tv.a, tv.b, tv.c, bary, dist);
+            if (hit && dist < tmax) {
+                if (isShadow) {
+                    occluded = true;
+                    node = end;
+                } else {
+                    hitPrim = pending;
+                    tmax = dist;
+                    hitBary = bary;
+                }
+            }
+            pending = -1;
+        }
+        // ---------------- retire finished traces ----------------
+        if (state == PS_TRACE && pending < 0 && node == end) {
+            if (isShadow) {
+                float nw = sNee[3][t];
+                if (!occluded && nw >= 0.f) {  // the `+=` of pathtrace.cu:201-207
+                    if (nw == 0.f) {
+                        sAccD[0][t] += sNee[0][t]; sAccD[1][t] += sNee[1][t]; sAccD[2][t] += sNee[2][t];
+                    } else {
+                        sAccI[0][t] += sNee[0][t]; sAccI[1][t] += sNee[1][t]; sAccI[2][t] += sNee[2][t];
+                    }
+                }
+                startExtensionOrFinish();
+            } else {
+                state = PS_SHADE;
+            }
+        }
+        // ---------------- shading ----------------
+        unsigned long long shadeM = __ballot(state == PS_SHADE);
+        if (shadeM != 0ull) {
+            bool canTrace = __ballot(state == PS_TRACE) != 0ull;
+            if (__popcll(shadeM) >= RD_SHADE_MIN || !canTrace) {
+                if (state == PS_SHADE) {
+                    v3 rayDir = rs.d;
+                    bool terminate = true;  // set false once a shadow or extension ray is started
+                    do {
+                        if (hitPrim == -1) {  // miss (pathtrace.cu:169-172 primary; :232-247 later, no env map)
+                            if (k == 0) sAccD[0][t] = sAccD[1][t] = sAccD[2][t] = 1.f;
+                            break;
+                        }
+                        nHits++;
+                        Surface isec;
+                        fetchSurface(s, hitPrim, hitBary, isec);
+                        Material material = loadMaterial(s.mats, isec.matId);
+                        v3 throughput;
+                        if (k == 0) {
+                            material.baseColor = mk3(1.f);  // DENOISER_DEMODULATE (:175-178)
+                            if (material.type == Light) {   // :179-182
+                                sAccD[0][t] = sAccD[1][t] = sAccD[2][t] = 1.f;
+                                break;
+                            }
+                            throughput = mk3(1.f);
+                        } else {
+                            throughput = mk3(sThr[0][t], sThr[1][t], sThr[2][t]);
+                            if (material.type == Light) {  // :251-271
+                                if (dot(isec.norm, rayDir) < 0.f) break;
+                                v3 radiance = material.baseColor;
+                                bool deltaSample = (sFlags[t] & 2) != 0;
+                                v3 curPos = mk3(sCur[0][t], sCur[1][t], sCur[2][t]);
+                                float weight = deltaSample
+                                                   ? 1.f
+                                                   : powerHeuristic(sExtPdf[t],
+                                                                    pdfAreaToSolidAngle(luminance(radiance) * s.sumLightPowerInv *
+                                                                                            getPrimitiveArea(s, isec.primId),
+                                                                                        curPos, isec.pos, isec.norm));
+                                v3 add = radiance * throughput * weight;
+                                sAccI[0][t] += add.x; sAccI[1][t] += add.y; sAccI[2][t] += add.z;
+                                break;
+                            }
+                        }
+                        const int depth = k + 1;
+                        if (depth > maxDepth) break;  // loop bound of pathtrace.cu:187
+                        isec.wo = -rayDir;
+                        bool deltaBSDF = (material.type == Dielectric);
+                        if (material.type != Dielectric && dot(isec.norm, isec.wo) < 0.f) isec.norm = -isec.norm;
+                        Sampler rng{s.sobol, rngScramble, rngPtr};
+                        bool emitShadow = false;
+                        v3 shadowTarget = mk3(0.f);
+                        if (!deltaBSDF) {  // NEE (:195-208)
+                            v4 r4 = sample4D(rng);
+                            if (s.lightSamplerLength != 0) {
+                                LightPick lp = pickLightPoint(s, r4);
+                                v3 radiance = mk3(0.f), wi = mk3(0.f);
+                                float lightPdf = lightPdfUnoccluded(s, isec.pos, lp, radiance, wi);
+                                v3 cc = mk3(0.f);
+                                float nw = -1.f;
+                                if (lightPdf > 0.f) {
+                                    float BSDFPdf = materialPdf(material, isec.norm, isec.wo, wi);
+                                    cc = throughput * materialBSDF(material, isec.norm, isec.wo, wi) * radiance *
+                                         satDot(isec.norm, wi) / lightPdf * powerHeuristic(lightPdf, BSDFPdf);
+                                    nw = depth == 1 ? 0.f : 1.f;
+                                }
+                                sNee[0][t] = cc.x; sNee[1][t] = cc.y; sNee[2][t] = cc.z; sNee[3][t] = nw;
+                                shadowTarget = lp.sampled;
+                                emitShadow = true;  // traced even if nothing can be added
+                            }
+                        }
+                        sCur[0][t] = isec.pos.x; sCur[1][t] = isec.pos.y; sCur[2][t] = isec.pos.z;
+                        BSDFSample sample;
+                        sample.pdf = 0.f;
+                        materialSample(material, isec.norm, isec.wo, sample3D(rng), sample);
+                        rngScramble = rng.scramble;
+                        rngPtr = rng.ptr;
+                        int flags = 0;
+                        if (!(sample.type == Invalid) && !(sample.pdf < 1e-8f)) {
+                            bool deltaSample = (sample.type & Specular) != 0;
+                            throughput = throughput * (sample.bsdf / sample.pdf * (deltaSample ? 1.f : absDot(isec.norm, sample.dir)));
+                            Ray ray = makeOffsetedRay(isec.pos, sample.dir);
+                            sExtO[0][t] = ray.o.x; sExtO[1][t] = ray.o.y; sExtO[2][t] = ray.o.z;
+                            sExtD[0][t] = ray.d.x; sExtD[1][t] = ray.d.y; sExtD[2][t] = ray.d.z;
+                            sExtPdf[t] = sample.pdf;
+                            sThr[0][t] = throughput.x; sThr[1][t] = throughput.y; sThr[2][t] = throughput.z;
+                            flags = 1 | (deltaSample ? 2 : 0);
+                        }
+                        sFlags[t] = flags;
+                        k = depth;
+                        terminate = false;
+                        if (emitShadow) startShadow(isec.pos, shadowTarget);
+                        else startExtensionOrFinish();
+                    } while (false);
+                    if (terminate) finishPixel();
+                }
+            }
+        }
+    }
+    if (COUNT) flushCounters(s.counters, nClosest, nAny, nHits, ws);
+}
+
+}  // namespace rd

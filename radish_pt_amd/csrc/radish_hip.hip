@@ -18,6 +18,7 @@
 #include "device/kernels_pt.h"
 #include "device/kernels_restir.h"
 #include "device/kernels_wave.h"
+#include "device/kernels_persist.h"
 
 using namespace rd;
 
@@ -34,6 +35,8 @@ struct rdh_ctx {
     DScene ds{};
     std::vector<void *> sceneAllocs;
     Counters *dCounters = nullptr;
+    PersistCounters *dPersist = nullptr;
+    unsigned persistGrid = 0;
 
     // camera
     bool haveCamera = false;
@@ -250,7 +253,8 @@ int rdh_create(rdh_ctx **out, int device) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
-        hipMalloc((void **)&c->dCounters, sizeof(Counters)) != hipSuccess) {
+        hipMalloc((void **)&c->dCounters, sizeof(Counters)) != hipSuccess ||
+        hipMalloc((void **)&c->dPersist, sizeof(PersistCounters)) != hipSuccess) {
         delete c;
         return RDH_ERR_NO_DEVICE;
     }
@@ -278,6 +282,7 @@ void rdh_destroy(rdh_ctx *c) {
     for (void *p : c->wfAllocs) hipFree(p);
     for (hipEvent_t e : c->profEvents) hipEventDestroy(e);
     if (c->dCounters) hipFree(c->dCounters);
+    if (c->dPersist) hipFree(c->dPersist);
     if (c->evStart) hipEventDestroy(c->evStart);
     if (c->evStop) hipEventDestroy(c->evStop);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
@@ -440,6 +445,32 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         rc = wavefrontPathTrace(c, pm, d_direct, d_indirect, iter, looper, maxDepth, flags);
         if (rc) return rc;
         return timeEnd(c, "pathTrace (wavefront)");
+    }
+    if (flags & RDH_PT_PERSISTENT) {
+        // one persistent launch: 4 workgroups per CU (the kernel's 116-VGPR / 24.6 KB-LDS budget), never more than
+        // there are 4-block groups of work
+        // The grid must be fully resident: a workgroup that starts late would start its static first blocks late.
+        unsigned groups = (((unsigned)(pm.numBlocks + 3) / 4 + 7u) / 8u) * 8u;
+        if (c->persistGrid == 0) {
+            int perCU = 0, cus = 0;
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_pt_persistent<false>, 256, 0));
+            HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            if (perCU < 1) perCU = 1;
+            if (perCU > 1) perCU -= 0;  // SGPR-heavy kernels: the API can over-report by one (MI355X_MICROARCH.md); VGPR-bound here
+            c->persistGrid = (unsigned)(perCU * cus);
+        }
+        unsigned grid = groups < c->persistGrid ? groups : c->persistGrid;
+        timeBegin(c);
+        HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, sizeof(PersistCounters), c->stream));
+        long pp = profBegin(c, flags);
+        if (count)
+            hipLaunchKernelGGL(k_pt_persistent<true>, dim3(grid), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+                               maxDepth, d_direct, d_indirect, c->dPersist);
+        else
+            hipLaunchKernelGGL(k_pt_persistent<false>, dim3(grid), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+                               maxDepth, d_direct, d_indirect, c->dPersist);
+        profEnd(c, pp);
+        return timeEnd(c, "pathTrace (persistent)");
     }
     timeBegin(c);
     long pe = profBegin(c, flags);

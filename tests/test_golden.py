@@ -85,7 +85,8 @@ def test_hip_reproduces_golden(golden, gpu_ctx):
     occ = torch.zeros(len(g["segments"]), dtype=torch.int32, device="cuda")
     ctx.trace_occluded(torch.from_numpy(g["segments"]).cuda(), occ)
     assert np.array_equal(occ.cpu().numpy(), g["occluded"])
-    for flags in (api.RDH_PT_MEGAKERNEL, api.RDH_PT_WAVEFRONT, api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL):
+    for flags in (api.RDH_PT_MEGAKERNEL, api.RDH_PT_WAVEFRONT, api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,
+                  api.RDH_PT_PERSISTENT):
         d = torch.zeros(n, 3, device="cuda")
         i = torch.zeros(n, 3, device="cuda")
         for it in range(4):

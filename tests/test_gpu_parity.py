@@ -103,14 +103,15 @@ def test_trace_empty_and_ragged(cornell_gpu, cornell_small):
 # ---------------------------------------------------------------------------------------------------------------------
 # pathTrace: megakernel and wavefront, several frames of accumulation
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("flags_name", ["mega", "wavefront", "wavefront_sort"])
+@pytest.mark.parametrize("flags_name", ["mega", "wavefront", "wavefront_sort", "persistent"])
 @pytest.mark.parametrize("size,depth", [((64, 48), 4), ((37, 29), 8)])
 def test_path_trace_bit_exact(cornell_gpu, cornell_small, flags_name, size, depth):
     from radish_pt_amd import api, scenes
 
     torch = _torch()
     flags = {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
-             "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL}[flags_name] | api.RDH_PT_COUNT
+             "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,
+             "persistent": api.RDH_PT_PERSISTENT}[flags_name] | api.RDH_PT_COUNT
     W, H = size
     cam = scenes.cornell_camera(W, H)
     o = _oracle(cornell_small)
@@ -143,7 +144,7 @@ def test_path_trace_depth_zero_and_one(cornell_gpu, cornell_small):
     cornell_gpu.set_camera(cam)
     o = _oracle(cornell_small)
     for depth in (0, 1):
-        for flags in (api.RDH_PT_MEGAKERNEL, api.RDH_PT_WAVEFRONT):
+        for flags in (api.RDH_PT_MEGAKERNEL, api.RDH_PT_WAVEFRONT, api.RDH_PT_PERSISTENT):
             ref_d = np.zeros((W * H, 3), np.float32)
             ref_i = np.zeros((W * H, 3), np.float32)
             o.path_trace(cam, ref_d, ref_i, 0, 3, depth)
@@ -236,13 +237,14 @@ def test_1080p_variants_agree(gpu_ctx, cornell_full):
     cam = scenes.cornell_camera(W, H)
     gpu_ctx.set_camera(cam)
     out = {}
-    for name, flags in (("mega", 0), ("wave", api.RDH_PT_WAVEFRONT), ("sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL)):
+    for name, flags in (("mega", 0), ("wave", api.RDH_PT_WAVEFRONT), ("sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL),
+                        ("persist", api.RDH_PT_PERSISTENT)):
         d = torch.zeros(W * H, 3, device="cuda")
         i = torch.zeros(W * H, 3, device="cuda")
         gpu_ctx.counters_reset()
         gpu_ctx.path_trace(d, i, 0, 0, 8, flags | api.RDH_PT_COUNT)
         out[name] = (d.cpu().numpy(), i.cpu().numpy(), gpu_ctx.counters())
-    for name in ("wave", "sort"):
+    for name in ("wave", "sort", "persist"):
         assert_bit_equal(out[name][0], out["mega"][0], f"{name} direct")
         assert_bit_equal(out[name][1], out["mega"][1], f"{name} indirect")
         assert out[name][2] == out["mega"][2]
@@ -279,7 +281,7 @@ def test_tile_partition_matches_frame(gpu_ctx, cornell_small):
             tpr = gpu_ctx.tiles_per_rank()
             d = torch.zeros(tpr * tile * tile, 3, device="cuda")
             i = torch.zeros(tpr * tile * tile, 3, device="cuda")
-            gpu_ctx.path_trace(d, i, 0, 9, 4, api.RDH_PT_WAVEFRONT if rank % 2 else api.RDH_PT_MEGAKERNEL)
+            gpu_ctx.path_trace(d, i, 0, 9, 4, (api.RDH_PT_WAVEFRONT, api.RDH_PT_MEGAKERNEL, api.RDH_PT_PERSISTENT)[rank % 3])
             shards_d.append(d)
             shards_i.append(i)
         frame_d = torch.zeros(W * H, 3, device="cuda")
