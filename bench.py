@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "wavefront"),
                     choices=["mega", "wavefront", "wavefront_sort", "persistent"])
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "teapots"])
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_small", "teapots", "teapots_lights"])
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -81,8 +81,9 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     W, H, depth = args.width, args.height, args.depth
-    sd = scenes.cornell() if args.scene == "cornell" else scenes.teapots()
-    cam = scenes.cornell_camera(W, H) if args.scene == "cornell" else scenes.teapots_camera(W, H)
+    sd = {"cornell": scenes.cornell, "cornell_small": lambda: scenes.cornell(segments=16, bands=12),
+          "teapots": scenes.teapots, "teapots_lights": lambda: scenes.teapots(emissive_grid=(16, 32))}[args.scene]()
+    cam = scenes.cornell_camera(W, H) if args.scene.startswith("cornell") else scenes.teapots_camera(W, H)
     ctx = api.Context(dev.index)
     ctx.upload_scene(sd)
     ctx.set_camera(cam)

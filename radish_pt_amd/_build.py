@@ -54,6 +54,16 @@ def build_hip(force=False):
     return out
 
 
+def build_variant(name, defines):
+    """Tuning builds: csrc/variants/libradish_hip_<name>.so compiled with extra -D flags (select with RADISH_HIP_LIB)."""
+    d = os.path.join(CSRC, "variants")
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, f"libradish_hip_{name}.so")
+    _run([HIPCC] + HIP_FLAGS + [f"-D{x}" for x in defines] + ["-I", os.path.join(ROOT, "include"), "-o", out]
+         + HIP_SOURCES + ["-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
 def build_all(force=False):
     build_host(force)
     build_hip(force)

@@ -23,7 +23,8 @@ import numpy as np
 from . import layouts as L
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libradish_hip.so")
+# RADISH_HIP_LIB selects an alternative build of the same library (tuning experiments); never a different backend.
+HIP_LIB_PATH = os.environ.get("RADISH_HIP_LIB") or os.path.join(_HERE, "csrc", "libradish_hip.so")
 
 RDH_PT_MEGAKERNEL, RDH_PT_WAVEFRONT, RDH_PT_SORT_MATERIAL, RDH_PT_COUNT, RDH_PT_PROFILE = 0, 1, 2, 4, 8
 RDH_PT_PERSISTENT = 16

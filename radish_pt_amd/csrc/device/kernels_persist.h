@@ -35,8 +35,11 @@ struct PersistCounters {
 
 constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
 
+#ifndef RD_PERSIST_WAVES
+#define RD_PERSIST_WAVES 1
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
+__global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
                                                        float *__restrict__ directIllum, float *__restrict__ indirectIllum,
                                                        PersistCounters *pc) {
     // ---- LDS-resident path state (SoA: lane-consecutive, conflict-free) ----
@@ -163,31 +166,29 @@ __global__ __launch_bounds__(256) void k_pt_persistent(DScene s, DCamera cam, Pi
         }
 
         // ---------------- box steps ----------------
-        for (;;) {
-            bool tracing = state == PS_TRACE;
-            bool walking = tracing && pending < 0 && node != end;
-            unsigned long long wm = __ballot(walking);
-            if (wm == 0ull) break;
-            unsigned long long pmk = __ballot(tracing && pending >= 0);
-            int nWalk = __popcll(wm), nPark = __popcll(pmk);
-            if (pmk != 0ull && nPark * RD_LEAF_DEN >= (nWalk + nPark) * RD_LEAF_NUM) break;
-            unsigned long long fin = __ballot(tracing && pending < 0 && node == end);  // traces waiting to retire
-            unsigned long long shd = __ballot(state == PS_SHADE);
-            int nIdleNow = 64 - nWalk - nPark - __popcll(fin) - __popcll(shd);
-            if (__popcll(fin) + __popcll(shd) >= RD_SHADE_MIN) break;
-            if (!exhausted && nIdleNow >= RD_PIX_REFILL_MIN) break;
-            if (walking) {
-                float4 lo = nodes[node].lo_prim;
-                float4 hi = nodes[node].hi_next;
-                float boundDist;
-                if (COUNT) ws.nodes++;
-                bool boundHit = boxTest(lo, hi, rs, boundDist);
-                if (boundHit && boundDist < tmax) {
-                    pending = __float_as_int(lo.w);
-                    node++;
-                } else {
-                    node = __float_as_int(hi.w);
-                }
+        // Run until a quarter of the lanes that entered the loop have stopped walking (parked on a leaf or finished
+        // their ray): one ballot + popcount per step is the whole scheduling cost.
+        {
+            bool walking = state == PS_TRACE && pending < 0 && node != end;
+            int nStart = __popcll(__ballot(walking));
+            if (nStart > 0) {
+                const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
+                do {
+                    if (walking) {
+                        float4 lo = nodes[node].lo_prim;
+                        float4 hi = nodes[node].hi_next;
+                        float boundDist;
+                        if (COUNT) ws.nodes++;
+                        bool boundHit = boxTest(lo, hi, rs, boundDist);
+                        if (boundHit && boundDist < tmax) {
+                            pending = __float_as_int(lo.w);
+                            node++;
+                        } else {
+                            node = __float_as_int(hi.w);
+                        }
+                        walking = pending < 0 && node != end;
+                    }
+                } while (__popcll(__ballot(walking)) >= (minWalk > 1 ? minWalk : 1));
             }
         }
         // ---------------- leaf tests of parked lanes ----------------

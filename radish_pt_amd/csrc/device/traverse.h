@@ -65,7 +65,7 @@ RD_DEV bool distMaxMin(float a1, float a2, float b1, float b2, float &tMin) {  /
     return (tMax >= 0.f && tMax >= tMin);
 }
 
-// AABB::intersect (bvh.h:91-155)
+// AABB::intersect (bvh.h:91-155), literal.
 RD_DEV bool aabbIntersect(v3 pMin, v3 pMax, const RaySlab &r, float &tMin) {
     const float Eps = 1e-6f;
     if (r.cls >= 1 && r.cls <= 3) {
@@ -169,15 +169,32 @@ RD_DEV bool aabbFast(float4 lo, float4 hi, const RaySlab &r, float &tMin) {
     float fx = __builtin_fmaxf(t1x, t2x), fy = __builtin_fmaxf(t1y, t2y), fz = __builtin_fmaxf(t1z, t2z);
     float dx = fx - nx, dy = fy - ny, dz = fz - nz;
     float yz = fz - ny, zx = fx - nz, xy = fy - nx;
-    bool overlap = (dy + dz > yz) && (dz + dx > zx) && (dx + dy > xy);
+    bool overlap = (dy + dz > yz) & (dz + dx > zx) & (dx + dy > xy);
     tMin = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
     float tMax = __builtin_fminf(__builtin_fminf(fx, fy), fz);
-    return overlap && tMax >= 0.f && tMax >= tMin;
+    return overlap & (tMax >= 0.f) & (tMax >= tMin);
+}
+
+// Out-of-line wrapper for the literal test: only rays with an axis-parallel, tiny or non-finite direction component
+// come here, and inlining it makes the compiler fuse it with the fast path of the hot loop.  Everything by value (an
+// address-taken RaySlab would be forced into scratch memory).  Returns {hit ? 1 : 0, tMin}.
+__device__ __attribute__((noinline)) float2 aabbSlow(float4 lo, float4 hi, float ox, float oy, float oz, float dx, float dy,
+                                                     float dz, float ix, float iy, float iz, int cls) {
+    RaySlab r;
+    r.o = mk3(ox, oy, oz);
+    r.d = mk3(dx, dy, dz);
+    r.inv = mk3(ix, iy, iz);
+    r.cls = cls;
+    float t = 0.f;
+    bool h = aabbIntersect(mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), r, t);
+    return make_float2(h ? 1.f : 0.f, t);
 }
 
 RD_DEV bool boxTest(float4 lo, float4 hi, const RaySlab &rs, float &t) {
     if (rs.cls == 0) return aabbFast(lo, hi, rs, t);
-    return aabbIntersect(mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), rs, t);
+    float2 r = aabbSlow(lo, hi, rs.o.x, rs.o.y, rs.o.z, rs.d.x, rs.d.y, rs.d.z, rs.inv.x, rs.inv.y, rs.inv.z, rs.cls);
+    t = r.y;
+    return r.x != 0.f;
 }
 
 // How many of the still-running lanes must be parked on a leaf before the wave leaves the box loop to run the
