@@ -81,6 +81,7 @@ typedef struct rdh_counters {
 #define RDH_PT_SORT_MATERIAL 2u/* wavefront only: bin hits by BSDF type before shading                      */
 #define RDH_PT_COUNT 4u        /* maintain rdh_counters (adds atomics; leave off when timing)               */
 #define RDH_PT_PERSISTENT 16u  /* one persistent launch: per-lane state machine with lane refill (kernels_persist.h) */
+#define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read            */
 
@@ -156,6 +157,10 @@ int rdh_counters_read(rdh_ctx *ctx, rdh_counters *out); /* blocking */
  * rdh_profile_reset, and how many launches that was (at most 8192 are recorded).  Both calls block. */
 int rdh_profile_reset(rdh_ctx *ctx);
 int rdh_profile_read(rdh_ctx *ctx, double *totalMs, int64_t *launches);
+
+/* Diagnostic builds only (-DRD_PERSIST_STAMPS): wall-clock stamps (100 MHz ticks) of the last persistent launch —
+ * [0][w] wave w started, [1][w] it found the pixel supply dry, [2][w] it ended.  RDH_ERR_UNSUPPORTED otherwise. */
+int rdh_debug_persist_stamps(rdh_ctx *ctx, uint64_t *out3x4096);
 
 /* Time of the most recent render call's kernels, measured with hipEvents on the context's stream (blocking);
  * the reference prints this figure from pathTrace (src/pathtrace.cu:364-374). */

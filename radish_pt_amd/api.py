@@ -28,6 +28,7 @@ HIP_LIB_PATH = os.environ.get("RADISH_HIP_LIB") or os.path.join(_HERE, "csrc", "
 
 RDH_PT_MEGAKERNEL, RDH_PT_WAVEFRONT, RDH_PT_SORT_MATERIAL, RDH_PT_COUNT, RDH_PT_PROFILE = 0, 1, 2, 4, 8
 RDH_PT_PERSISTENT = 16
+RDH_PT_NO_SCHEDULE = 32
 SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12
 
 # Every symbol include/radish_hip.h declares (tests check that the library exports all of them).
@@ -36,7 +37,7 @@ EXPORTS = [
     "rdh_scene_free", "rdh_set_camera", "rdh_set_partition", "rdh_tiles_per_rank", "rdh_untile", "rdh_path_trace",
     "rdh_path_trace_direct", "rdh_gbuffer_render", "rdh_restir_init", "rdh_restir_free", "rdh_restir_direct",
     "rdh_restir_read", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
-    "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read",
+    "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps",
 ]
 
 
@@ -113,6 +114,7 @@ def lib():
             "rdh_last_kernel_ms": ([vp, C.POINTER(C.c_float)], i32),
             "rdh_profile_reset": ([vp], i32),
             "rdh_profile_read": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)], i32),
+            "rdh_debug_persist_stamps": ([vp, vp], i32),
         }
         for name, (args, res) in sig.items():
             fn = getattr(l, name)
@@ -248,6 +250,11 @@ class Context:
         ms, n = C.c_double(0), C.c_int64(0)
         self.check(lib().rdh_profile_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def debug_persist_stamps(self):
+        out = np.zeros((3, 4096), dtype=np.uint64)
+        self.check(lib().rdh_debug_persist_stamps(self.h, out.ctypes.data))
+        return out
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

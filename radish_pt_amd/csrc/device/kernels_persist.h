@@ -31,9 +31,53 @@ namespace rd {
 
 struct PersistCounters {
     int blockHead;  // next 8x8 pixel block beyond the static first round (see k_pt_persistent)
+    int pad;
+#ifdef RD_PERSIST_STAMPS  // diagnostic build only: when each wave started, ran out of pixels, and ended (wall clock)
+    unsigned long long stamp[3][4096];
+#endif
 };
 
 constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
+
+// ---- longest-paths-first block order ---------------------------------------------------------------------------
+// A persistent launch ends one path-latency after the pixel supply runs dry (measured: supply dry at ~1.9 ms, last
+// wave out at ~3.8 ms on the Cornell frame), so the blocks holding long paths must start first.  Each launch records,
+// per 8x8 block, the largest number of box steps any of its paths took; the next launch visits blocks in descending
+// order of that figure (frames of an animation are coherent; the first frame uses plain order).  Pure scheduling:
+// which lane renders a pixel, and when, cannot change its value.
+constexpr int kCostBuckets = 64;
+__global__ __launch_bounds__(1024) void k_persist_schedule(unsigned *__restrict__ cost, int *__restrict__ order, int n) {
+    __shared__ int hist[kCostBuckets], base[kCostBuckets];
+    const int t = int(threadIdx.x);
+    if (t < kCostBuckets) hist[t] = 0;
+    __syncthreads();
+    auto bucketOf = [](unsigned c) {  // quarter-octave buckets, descending: bucket 0 = most expensive
+        int b = 0;
+        if (c > 0) {
+            int lg = 31 - __clz((int)c);                         // floor(log2 c)
+            int frac = lg >= 2 ? int((c >> (lg - 2)) & 3u) : 0;  // next two bits
+            b = lg * 4 + frac + 1;
+        }
+        if (b > kCostBuckets - 1) b = kCostBuckets - 1;
+        return kCostBuckets - 1 - b;
+    };
+    for (int i = t; i < n; i += 1024) atomicAdd(&hist[bucketOf(cost[i])], 1);
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int b = 0; b < kCostBuckets; b++) {
+            base[b] = acc;
+            acc += hist[b];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {  // order inside a bucket is arrival order: ties are equally expensive
+        int pos = atomicAdd(&base[bucketOf(cost[i])], 1);
+        order[pos] = i;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) cost[i] = 0u;
+}
 
 #ifndef RD_PERSIST_WAVES
 #define RD_PERSIST_WAVES 1
@@ -41,7 +85,8 @@ constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
 template <bool COUNT>
 __global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
                                                        float *__restrict__ directIllum, float *__restrict__ indirectIllum,
-                                                       PersistCounters *pc) {
+                                                       PersistCounters *pc, const int *__restrict__ blockOrder,
+                                                       unsigned *__restrict__ blockCost) {
     // ---- LDS-resident path state (SoA: lane-consecutive, conflict-free) ----
     __shared__ float sThr[3][256], sAccD[3][256], sAccI[3][256], sCur[3][256];
     __shared__ float sExtO[3][256], sExtD[3][256], sExtPdf[256], sNee[4][256];
@@ -51,10 +96,15 @@ __global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene 
     const int end = s.bvhSize;
     const int numBlocks = pm.numBlocks;
     // xcdSwizzle is a bijection on the group range padded to a multiple of 8: walk the padded range, skip the padding
-    const int paddedBlocks = int((((unsigned)(numBlocks + 3) / 4u + 7u) / 8u) * 8u * 4u);
+    const int paddedBlocks = blockOrder ? numBlocks : int((((unsigned)(numBlocks + 3) / 4u + 7u) / 8u) * 8u * 4u);
 
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
+#ifdef RD_PERSIST_STAMPS
+    const int gw = int(blockIdx.x * 4u + (threadIdx.x >> 6));
+    bool stampedDry = false;
+    if (lane == 0 && gw < 4096) pc->stamp[0][gw] = wall_clock64();
+#endif
 
     // wave-uniform pixel reservation: one 8x8 block at a time; the first is static (wave g takes block g)
     int curBlock = int(blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -65,6 +115,8 @@ __global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene 
     // per-lane registers
     int state = PS_IDLE;
     int outIdx = 0;
+    int myBlock = 0;         // 8x8 block this lane's pixel belongs to (index into blockCost)
+    unsigned pathSteps = 0;  // box steps of the current path
     int k = 0;  // index of the hit the current extension ray leads to (0 = primary)
     uint32_t rngScramble = 0;
     int rngPtr = 0;
@@ -105,6 +157,7 @@ __global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene 
         indirect = HDRToLDR(indirect);
         storeRunningMean(directIllum, outIdx, direct, iter);
         storeRunningMean(indirectIllum, outIdx, indirect, iter);
+        atomicMax(&blockCost[myBlock], pathSteps);
         state = PS_IDLE;
     };
     auto startExtensionOrFinish = [&]() {
@@ -138,13 +191,22 @@ __global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene 
                 int avail = 64 - slotNext;
                 int give = (nIdle - taken) < avail ? (nIdle - taken) : avail;
                 if (state == PS_IDLE && myRank >= taken && myRank < taken + give) {
-                    // XCD-aware block order as in the one-shot kernels: workgroup-sized groups of 4 blocks
-                    unsigned wgLogical;
-                    bool ok = xcdSwizzle((unsigned)curBlock >> 2, (unsigned)(numBlocks + 3) >> 2, wgLogical);
-                    Pix px = mapPixel(pm, ok ? wgLogical * 4u + ((unsigned)curBlock & 3u) : 0xffffffffu / 64u,
-                                      (unsigned)(slotNext + (myRank - taken)));
+                    // block to render: the scheduled order if there is one, else XCD-aware plain order (workgroup-sized
+                    // groups of 4 blocks, as in the one-shot kernels)
+                    unsigned blk;
+                    bool ok = true;
+                    if (blockOrder) {
+                        blk = (unsigned)blockOrder[curBlock];
+                    } else {
+                        unsigned wgLogical;
+                        ok = xcdSwizzle((unsigned)curBlock >> 2, (unsigned)(numBlocks + 3) >> 2, wgLogical);
+                        blk = ok ? wgLogical * 4u + ((unsigned)curBlock & 3u) : 0xffffffffu / 64u;
+                    }
+                    Pix px = mapPixel(pm, blk, (unsigned)(slotNext + (myRank - taken)));
                     if (px.valid && ok) {
                         outIdx = px.out;
+                        myBlock = int(blk);
+                        pathSteps = 0;
                         Sampler rng = makeSeededRandomEngine(looper, px.index, 0, s.sobol);
                         Ray ray = cameraSample(cam, px.x, px.y, sample4D(rng));
                         rngScramble = rng.scramble;
@@ -164,6 +226,12 @@ __global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene 
             if (exhausted) break;
             continue;
         }
+#ifdef RD_PERSIST_STAMPS
+        if (exhausted && !stampedDry) {
+            stampedDry = true;
+            if (lane == 0 && gw < 4096) pc->stamp[1][gw] = wall_clock64();
+        }
+#endif
 
         // ---------------- box steps ----------------
         // Run until a quarter of the lanes that entered the loop have stopped walking (parked on a leaf or finished
@@ -179,6 +247,7 @@ __global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene 
                         float4 hi = nodes[node].hi_next;
                         float boundDist;
                         if (COUNT) ws.nodes++;
+                        pathSteps++;
                         bool boundHit = boxTest(lo, hi, rs, boundDist);
                         if (boundHit && boundDist < tmax) {
                             pending = __float_as_int(lo.w);
@@ -324,6 +393,9 @@ __global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene 
             }
         }
     }
+#ifdef RD_PERSIST_STAMPS
+    if (lane == 0 && gw < 4096) pc->stamp[2][gw] = wall_clock64();
+#endif
     if (COUNT) flushCounters(s.counters, nClosest, nAny, nHits, ws);
 }
 

@@ -114,7 +114,6 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
     const int *rayq = w.rayq[k & 1];
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
-    const int lane = int(threadIdx.x & 63u);
     const int end = s.bvhSize;
 
     // wave-uniform reservation of work items; the first one is static (see wavePull)

@@ -37,6 +37,10 @@ struct rdh_ctx {
     Counters *dCounters = nullptr;
     PersistCounters *dPersist = nullptr;
     unsigned persistGrid = 0;
+    unsigned *blockCost = nullptr;  // per-8x8-block cost of the previous persistent launch (k_persist_schedule)
+    int *blockOrder = nullptr;
+    int costBlocks = 0;             // blocks the two arrays are sized / valid for
+    bool orderValid = false;
 
     // camera
     bool haveCamera = false;
@@ -283,6 +287,8 @@ void rdh_destroy(rdh_ctx *c) {
     for (hipEvent_t e : c->profEvents) hipEventDestroy(e);
     if (c->dCounters) hipFree(c->dCounters);
     if (c->dPersist) hipFree(c->dPersist);
+    if (c->blockCost) hipFree(c->blockCost);
+    if (c->blockOrder) hipFree(c->blockOrder);
     if (c->evStart) hipEventDestroy(c->evStart);
     if (c->evStop) hipEventDestroy(c->evStop);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
@@ -350,7 +356,9 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
     if ((rc = uploadVec(c, attrs, &c->ds.attrs))) return rc;
     if ((rc = uploadVec(c, mats, &c->ds.mats))) return rc;
 
-    std::vector<NodeRec> nodes(S);
+    std::vector<NodeRec> nodes(S + 1);  // +1: a readable pad record at index S (speculative next-node loads)
+    nodes[S].lo_prim = make_float4(0.f, 0.f, 0.f, asFloat(-1));
+    nodes[S].hi_next = make_float4(0.f, 0.f, 0.f, asFloat(S));
     for (int k = 0; k < 6; k++) {
         const int32_t *src = d->bvhNodes[k];
         for (int i = 0; i < S; i++) {
@@ -391,6 +399,7 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
     c->ds.lightSamplerLength = d->lightSamplerLength;
     c->ds.sumLightPowerInv = d->sumLightPowerInv;
     c->haveScene = true;
+    c->orderValid = false;
     return RDH_OK;
 }
 
@@ -398,6 +407,7 @@ int rdh_set_camera(rdh_ctx *c, const void *camera196) {
     if (!c || !camera196) return RDH_ERR_ARGS;
     DCamera d = toDeviceCamera(camera196);
     if (d.resx <= 0 || d.resy <= 0) return fail(c, RDH_ERR_ARGS, "camera resolution %dx%d", d.resx, d.resy);
+    if (d.resx != c->cam.resx || d.resy != c->cam.resy) c->orderValid = false;
     c->cam = d;
     c->haveCamera = true;
     return RDH_OK;
@@ -406,6 +416,7 @@ int rdh_set_camera(rdh_ctx *c, const void *camera196) {
 int rdh_set_partition(rdh_ctx *c, int rank, int world, int tileSize) {
     if (!c || world < 1 || rank < 0 || rank >= world || tileSize < 8 || (tileSize % 8) != 0)
         return fail(c, RDH_ERR_ARGS, "rdh_set_partition(rank=%d, world=%d, tile=%d)", rank, world, tileSize);
+    if (rank != c->rank || world != c->world || tileSize != c->tile) c->orderValid = false;
     c->rank = rank;
     c->world = world;
     c->tile = tileSize;
@@ -460,16 +471,35 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
             c->persistGrid = (unsigned)(perCU * cus);
         }
         unsigned grid = groups < c->persistGrid ? groups : c->persistGrid;
+        // longest-paths-first schedule from the previous launch's per-block costs (same partition and resolution only)
+        if (c->costBlocks != pm.numBlocks) {
+            if (c->blockCost) hipFree(c->blockCost);
+            if (c->blockOrder) hipFree(c->blockOrder);
+            c->blockCost = nullptr;
+            c->blockOrder = nullptr;
+            HIP_TRY(c, hipMalloc((void **)&c->blockCost, sizeof(unsigned) * (size_t)pm.numBlocks));
+            HIP_TRY(c, hipMalloc((void **)&c->blockOrder, sizeof(int) * (size_t)pm.numBlocks));
+            HIP_TRY(c, hipMemsetAsync(c->blockCost, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
+            c->costBlocks = pm.numBlocks;
+            c->orderValid = false;
+        }
         timeBegin(c);
+        const bool useOrder = c->orderValid && !(flags & RDH_PT_NO_SCHEDULE);
+        if (useOrder)
+            hipLaunchKernelGGL(k_persist_schedule, dim3(1), dim3(1024), 0, c->stream, c->blockCost, c->blockOrder, pm.numBlocks);
+        else
+            HIP_TRY(c, hipMemsetAsync(c->blockCost, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, sizeof(PersistCounters), c->stream));
+        const int *order = useOrder ? c->blockOrder : nullptr;
         long pp = profBegin(c, flags);
         if (count)
             hipLaunchKernelGGL(k_pt_persistent<true>, dim3(grid), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter,
-                               maxDepth, d_direct, d_indirect, c->dPersist);
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost);
         else
             hipLaunchKernelGGL(k_pt_persistent<false>, dim3(grid), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter,
-                               maxDepth, d_direct, d_indirect, c->dPersist);
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost);
         profEnd(c, pp);
+        c->orderValid = true;
         return timeEnd(c, "pathTrace (persistent)");
     }
     timeBegin(c);
@@ -680,6 +710,17 @@ int rdh_profile_read(rdh_ctx *c, double *totalMs, int64_t *launches) {
     *totalMs = sum;
     *launches = (int64_t)c->profUsed;
     return RDH_OK;
+}
+
+int rdh_debug_persist_stamps(rdh_ctx *c, uint64_t *out3x4096) {
+    if (!c || !out3x4096) return RDH_ERR_ARGS;
+#ifdef RD_PERSIST_STAMPS
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out3x4096, c->dPersist->stamp, sizeof(unsigned long long) * 3 * 4096, hipMemcpyDeviceToHost));
+    return RDH_OK;
+#else
+    return fail(c, RDH_ERR_UNSUPPORTED, "library built without RD_PERSIST_STAMPS");
+#endif
 }
 
 int rdh_last_kernel_ms(rdh_ctx *c, float *ms) {
