@@ -7,6 +7,10 @@ renders Sobol row `looper = s` with `iter = 0` (the reference app resets `iterat
 device-resident image buffers.
 
 N = 1:  one process, one GPU, frame layout.
+Frames in flight (default 2): consecutive frames are independent (iter = 0), so frame s+1 is issued on a second HIP
+stream into its own buffers while frame s is still draining its last long paths; every frame is rendered completely and
+ms_per_step = wall time of the K frames / K.  `--frames-in-flight 1` gives the strictly serial figure.
+
 N > 1:  launched by torch.distributed.run, one rank per GPU.  The frame is cut into 64x64 tiles, tile t → rank t % N
         (strong scaling: the frame is fixed, per-GPU work shrinks).  Each rank traces its tiles into packed tile
         buffers; the finished tiles are exchanged with ONE RCCL all-gather per image per frame (all_gather_into_tensor
@@ -16,13 +20,15 @@ value = (closest-hit + any-hit rays actually traced in the K timed frames, all r
 Ray counts are exact device counters taken in an untimed pass over the same Sobol rows (the counters cost atomics,
 so the timed pass runs without them; the rays traced are identical).
 
-roofline: the dominant kernel is the traversal kernel (k_wf_trace in wavefront mode, the megakernel otherwise).
+roofline: the dominant kernel is the one that traverses (k_pt_persistent by default; k_wf_trace in wavefront mode,
+k_path_trace_mega in megakernel mode).
 `achieved` = algorithmic bytes ÷ the hipEvent-measured duration of its launches during the timed steps, with
   B = 40·closestRays + 28·anyRays + 32·nodeVisits + 36·triTests + 64·closestHits          
 (ray in 24 B + hit record 16 B / occlusion flag 4 B; 32 B per box step; 36 B per triangle test; 64 B of normals, uvs and
 material id per found hit), against the 8.0 TB/s HBM3E peak.
 
-cpu_baseline: the oracle (CPU restatement, single thread) timed on every 3rd pixel of the same frame, rank 0, N = 1 only.
+cpu_baseline: the oracle (CPU restatement, single thread) timed on one whole frame of the same workload, rank 0, N = 1
+only; its image doubles as a full-frame bit-exact parity check of the timed configuration (`parity_check`).
 """
 import argparse
 import json
@@ -49,11 +55,13 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "wavefront"),
+    ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "persistent"),
                     choices=["mega", "wavefront", "wavefront_sort", "persistent"])
     ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_small", "teapots", "teapots_lights"])
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RADISH_FRAMES_IN_FLIGHT", "2")),
+                    help="frames rendered concurrently, each on its own HIP stream into its own image buffers")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,34 +92,53 @@ def main():
     sd = {"cornell": scenes.cornell, "cornell_small": lambda: scenes.cornell(segments=16, bands=12),
           "teapots": scenes.teapots, "teapots_lights": lambda: scenes.teapots(emissive_grid=(16, 32))}[args.scene]()
     cam = scenes.cornell_camera(W, H) if args.scene.startswith("cornell") else scenes.teapots_camera(W, H)
-    ctx = api.Context(dev.index)
-    ctx.upload_scene(sd)
-    ctx.set_camera(cam)
-    ctx.set_partition(rank, world, args.tile)
     flags = {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
              "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,
              "persistent": api.RDH_PT_PERSISTENT}[args.mode]
 
-    if world == 1:
-        direct = torch.zeros(W * H, 3, device=dev)
-        indirect = torch.zeros(W * H, 3, device=dev)
-    else:
-        tpr = ctx.tiles_per_rank()
-        shard = tpr * args.tile * args.tile
-        direct = torch.zeros(shard, 3, device=dev)
-        indirect = torch.zeros(shard, 3, device=dev)
-        gath_d = torch.zeros(world * shard, 3, device=dev)
-        gath_i = torch.zeros(world * shard, 3, device=dev)
-        frame_d = torch.zeros(W * H, 3, device=dev)
-        frame_i = torch.zeros(W * H, 3, device=dev)
+    # One "slot" per frame in flight: its own context (stream, persistent-kernel workspace) and its own image buffers,
+    # so consecutive frames are independent (iter = 0: each frame overwrites its images) and can overlap on the GPU —
+    # the tail of frame s, where a few long paths are still running, is filled by the start of frame s+1.
+    F = max(1, args.frames_in_flight)
+
+    class Slot:
+        pass
+
+    slots = []
+    for f in range(F):
+        sl = Slot()
+        sl.stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(sl.stream):
+            sl.ctx = api.Context(dev.index)  # binds to the current torch stream = sl.stream
+            sl.ctx.upload_scene(sd)
+            sl.ctx.set_camera(cam)
+            sl.ctx.set_partition(rank, world, args.tile)
+            if world == 1:
+                sl.direct = torch.zeros(W * H, 3, device=dev)
+                sl.indirect = torch.zeros(W * H, 3, device=dev)
+            else:
+                tpr = sl.ctx.tiles_per_rank()
+                shard = tpr * args.tile * args.tile
+                sl.direct = torch.zeros(shard, 3, device=dev)
+                sl.indirect = torch.zeros(shard, 3, device=dev)
+                sl.gath_d = torch.zeros(world * shard, 3, device=dev)
+                sl.gath_i = torch.zeros(world * shard, 3, device=dev)
+                sl.frame_d = torch.zeros(W * H, 3, device=dev)
+                sl.frame_i = torch.zeros(W * H, 3, device=dev)
+        slots.append(sl)
+    torch.cuda.synchronize()
+    ctx = slots[0].ctx
+    direct, indirect = slots[0].direct, slots[0].indirect
 
     def step(s, f):
-        ctx.path_trace(direct, indirect, 0, s % api.SOBOL_SAMPLE_NUM, depth, f)
-        if world > 1:
-            dist.all_gather_into_tensor(gath_d, direct)
-            dist.all_gather_into_tensor(gath_i, indirect)
-            ctx.untile(gath_d, frame_d)
-            ctx.untile(gath_i, frame_i)
+        sl = slots[s % F]
+        with torch.cuda.stream(sl.stream):
+            sl.ctx.path_trace(sl.direct, sl.indirect, 0, s % api.SOBOL_SAMPLE_NUM, depth, f)
+            if world > 1:
+                dist.all_gather_into_tensor(sl.gath_d, sl.direct)
+                dist.all_gather_into_tensor(sl.gath_i, sl.indirect)
+                sl.ctx.untile(sl.gath_d, sl.frame_d)
+                sl.ctx.untile(sl.gath_i, sl.frame_i)
 
     def barrier():
         torch.cuda.synchronize()
@@ -124,19 +151,31 @@ def main():
     for s in range(Wm):
         step(s, flags)
     torch.cuda.synchronize()
-    ctx.counters_reset()
+    for sl in slots:
+        sl.ctx.counters_reset()
     for s in range(Wm, Wm + K):
-        ctx.path_trace(direct, indirect, 0, s % api.SOBOL_SAMPLE_NUM, depth, flags | api.RDH_PT_COUNT)
-    counters = ctx.counters()
+        sl = slots[s % F]
+        with torch.cuda.stream(sl.stream):
+            sl.ctx.path_trace(sl.direct, sl.indirect, 0, s % api.SOBOL_SAMPLE_NUM, depth, flags | api.RDH_PT_COUNT)
+    torch.cuda.synchronize()
+    counters = {}
+    for sl in slots:
+        for key, val in sl.ctx.counters().items():
+            counters[key] = counters.get(key, 0) + val
 
-    ctx.profile_reset()
+    for sl in slots:
+        sl.ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for s in range(Wm, Wm + K):
         step(s, flags | api.RDH_PT_PROFILE)
     barrier()
     elapsed = time.perf_counter() - t0
-    trace_ms, trace_launches = ctx.profile_read()
+    trace_ms, trace_launches = 0.0, 0
+    for sl in slots:
+        ms, n = sl.ctx.profile_read()
+        trace_ms += ms
+        trace_launches += n
 
     rays_local = counters["closestRays"] + counters["anyRays"]
     stats = torch.tensor([elapsed, float(rays_local), float(algorithmic_bytes(counters)), trace_ms, float(trace_launches)],
@@ -171,7 +210,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} stand-in ({sd.num_prims} tris), {W}x{H}, {depth} bounces, 1 spp/frame, "
                                    f"pathTrace ({args.mode}), tile-partitioned x{world}",
-                       "rays_per_frame": rays_total / K, "mode": args.mode, "parallelism": f"tile{args.tile}x{world}"},
+                       "rays_per_frame": rays_total / K, "mode": args.mode, "parallelism": f"tile{args.tile}x{world}",
+                       "frames_in_flight": F},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": ("k_wf_trace" if flags & api.RDH_PT_WAVEFRONT else
@@ -185,7 +225,7 @@ def main():
             o = pyoracle.OracleScene(sd)
             ref_d = np.zeros((W * H, 3), np.float32)
             ref_i = np.zeros((W * H, 3), np.float32)
-            stride = 3
+            stride = 1  # the whole frame: ~6 s of single-thread CPU work, and a full-frame parity check for free
             if hasattr(os, "sched_setaffinity"):
                 try:
                     os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
@@ -198,7 +238,7 @@ def main():
             cpu_rays = st["closestRays"] + st["anyRays"]
             out["cpu_baseline"] = {
                 "value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-                "sample": f"oracle pathTrace on every {stride}rd pixel of the same {W}x{H} depth-{depth} frame "
+                "sample": f"oracle pathTrace on every pixel (stride {stride}) of the same {W}x{H} depth-{depth} frame "
                           f"(looper {Wm}): {cpu_rays} rays in {cpu_s:.1f} s",
             }
             # parity spot check on the timed configuration: the sampled pixels must equal the GPU frame bit for bit
@@ -214,7 +254,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for sl in slots:
+        sl.ctx.close()
 
 
 if __name__ == "__main__":

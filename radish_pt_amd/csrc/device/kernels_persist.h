@@ -83,14 +83,16 @@ __global__ __launch_bounds__(1024) void k_persist_schedule(unsigned *__restrict_
 #define RD_PERSIST_WAVES 1
 #endif
 template <bool COUNT>
-__global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
+__global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
                                                        float *__restrict__ directIllum, float *__restrict__ indirectIllum,
                                                        PersistCounters *pc, const int *__restrict__ blockOrder,
                                                        unsigned *__restrict__ blockCost) {
     // ---- LDS-resident path state (SoA: lane-consecutive, conflict-free) ----
-    __shared__ float sThr[3][256], sAccD[3][256], sAccI[3][256], sCur[3][256];
-    __shared__ float sExtO[3][256], sExtD[3][256], sExtPdf[256], sNee[4][256];
-    __shared__ int sFlags[256];  // bit0: extension ray pending, bit1: that sample was specular
+    // One wave per workgroup: nothing here needs a workgroup barrier, and a finished wave frees its CU slot at once
+    // (with 4-wave workgroups the slot stays taken until the slowest of the four has drained its last path).
+    __shared__ float sThr[3][64], sAccD[3][64], sAccI[3][64], sCur[3][64];
+    __shared__ float sExtO[3][64], sExtD[3][64], sExtPdf[64], sNee[4][64];
+    __shared__ int sFlags[64];  // bit0: extension ray pending, bit1: that sample was specular
     const int t = int(threadIdx.x);
     const int lane = t & 63;
     const int end = s.bvhSize;
@@ -101,15 +103,15 @@ __global__ __launch_bounds__(256, RD_PERSIST_WAVES) void k_pt_persistent(DScene 
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
 #ifdef RD_PERSIST_STAMPS
-    const int gw = int(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const int gw = int(blockIdx.x);
     bool stampedDry = false;
     if (lane == 0 && gw < 4096) pc->stamp[0][gw] = wall_clock64();
 #endif
 
     // wave-uniform pixel reservation: one 8x8 block at a time; the first is static (wave g takes block g)
-    int curBlock = int(blockIdx.x * 4u + (threadIdx.x >> 6));
+    int curBlock = int(blockIdx.x);
     int slotNext = 0;  // next unassigned pixel slot (0..63) of curBlock
-    const int gridWavesN = int(gridDim.x * 4u);
+    const int gridWavesN = int(gridDim.x);
     bool exhausted = curBlock >= paddedBlocks;
 
     // per-lane registers

@@ -461,10 +461,10 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         // one persistent launch: 4 workgroups per CU (the kernel's 116-VGPR / 24.6 KB-LDS budget), never more than
         // there are 4-block groups of work
         // The grid must be fully resident: a workgroup that starts late would start its static first blocks late.
-        unsigned groups = (((unsigned)(pm.numBlocks + 3) / 4 + 7u) / 8u) * 8u;
+        unsigned groups = (((unsigned)(pm.numBlocks + 3) / 4 + 7u) / 8u) * 8u * 4u;  // one wave per workgroup
         if (c->persistGrid == 0) {
             int perCU = 0, cus = 0;
-            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_pt_persistent<false>, 256, 0));
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_pt_persistent<false>, 64, 0));
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             if (perCU < 1) perCU = 1;
             if (perCU > 1) perCU -= 0;  // SGPR-heavy kernels: the API can over-report by one (MI355X_MICROARCH.md); VGPR-bound here
@@ -493,10 +493,10 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         const int *order = useOrder ? c->blockOrder : nullptr;
         long pp = profBegin(c, flags);
         if (count)
-            hipLaunchKernelGGL(k_pt_persistent<true>, dim3(grid), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+            hipLaunchKernelGGL(k_pt_persistent<true>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
                                maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost);
         else
-            hipLaunchKernelGGL(k_pt_persistent<false>, dim3(grid), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+            hipLaunchKernelGGL(k_pt_persistent<false>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
                                maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost);
         profEnd(c, pp);
         c->orderValid = true;
