@@ -82,11 +82,19 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # Rehearsal hooks (one-GPU boxes): RADISH_FORCE_DEVICE puts every rank on one device, RADISH_DIST_BACKEND=gloo
+        # replaces RCCL, which refuses two ranks on one GPU.  The driver's N>1 runs use neither.
+        dev_index = int(os.environ.get("RADISH_FORCE_DEVICE", local_rank))
+        backend = os.environ.get("RADISH_DIST_BACKEND", "nccl")
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     W, H, depth = args.width, args.height, args.depth
     sd = {"cornell": scenes.cornell, "cornell_small": lambda: scenes.cornell(segments=16, bands=12),
@@ -242,7 +250,9 @@ def main():
                           f"(looper {Wm}): {cpu_rays} rays in {cpu_s:.1f} s",
             }
             # parity spot check on the timed configuration: the sampled pixels must equal the GPU frame bit for bit
-            ctx.path_trace(direct, indirect, 0, Wm, depth, flags)
+            with torch.cuda.stream(slots[0].stream):
+                ctx.path_trace(direct, indirect, 0, Wm, depth, flags)
+            ctx.synchronize()
             idx = np.arange(0, W * H, stride)
             g_d, g_i = direct.cpu().numpy(), indirect.cpu().numpy()
             ok = (np.array_equal(g_d[idx].view(np.uint32), ref_d[idx].view(np.uint32))

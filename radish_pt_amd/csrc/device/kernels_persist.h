@@ -46,7 +46,9 @@ constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
 // order of that figure (frames of an animation are coherent; the first frame uses plain order).  Pure scheduling:
 // which lane renders a pixel, and when, cannot change its value.
 constexpr int kCostBuckets = 64;
-__global__ __launch_bounds__(1024) void k_persist_schedule(unsigned *__restrict__ cost, int *__restrict__ order, int n) {
+// 256 threads, <= 64 VGPRs: fits beside a chip full of persistent waves (3 x 131 VGPRs per SIMD leave room for one more
+// small wave), so with two frames in flight the next frame's schedule does not queue behind the current frame's tail.
+__global__ __launch_bounds__(256) void k_persist_schedule(unsigned *__restrict__ cost, int *__restrict__ order, int n) {
     __shared__ int hist[kCostBuckets], base[kCostBuckets];
     const int t = int(threadIdx.x);
     if (t < kCostBuckets) hist[t] = 0;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(1024) void k_persist_schedule(unsigned *__restrict_
         if (b > kCostBuckets - 1) b = kCostBuckets - 1;
         return kCostBuckets - 1 - b;
     };
-    for (int i = t; i < n; i += 1024) atomicAdd(&hist[bucketOf(cost[i])], 1);
+    for (int i = t; i < n; i += 256) atomicAdd(&hist[bucketOf(cost[i])], 1);
     __syncthreads();
     if (t == 0) {
         int acc = 0;
@@ -71,12 +73,12 @@ __global__ __launch_bounds__(1024) void k_persist_schedule(unsigned *__restrict_
         }
     }
     __syncthreads();
-    for (int i = t; i < n; i += 1024) {  // order inside a bucket is arrival order: ties are equally expensive
+    for (int i = t; i < n; i += 256) {  // order inside a bucket is arrival order: ties are equally expensive
         int pos = atomicAdd(&base[bucketOf(cost[i])], 1);
         order[pos] = i;
     }
     __syncthreads();
-    for (int i = t; i < n; i += 1024) cost[i] = 0u;
+    for (int i = t; i < n; i += 256) cost[i] = 0u;
 }
 
 #ifndef RD_PERSIST_WAVES
@@ -235,6 +237,31 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         }
 #endif
 
+        // ---------------- literal-class rays: traced whole by the whole wave (traverse.h, coopTraceWhole) ----------------
+        {
+            unsigned long long lit = __ballot(state == PS_TRACE && rs.cls != 0 && node == 0 && pending < 0 && end != 0);
+            while (lit) {
+                const int L = __ffsll((long long)lit) - 1;
+                lit &= lit - 1ull;
+                const bool shadowL = readlaneI(isShadow ? 1 : 0, L) != 0;
+                const NodeRec *un = readlanePtr(nodes, L);
+                const RaySlab ur = readlaneRay(rs, L);
+                const float lim = readlaneF(tmax, L);
+                CoopTrace ct = shadowL ? coopTraceWhole<true>(s, un, ur, lim) : coopTraceWhole<false>(s, un, ur, lim);
+                if (lane == L) {
+                    hitPrim = ct.hitPrim;
+                    hitBary = ct.bary;
+                    tmax = ct.tmax;
+                    occluded = ct.found;
+                    node = end;
+                    pathSteps += ct.nodes;
+                    if (COUNT) {
+                        ws.nodes += ct.nodes;
+                        ws.tris += ct.tris;
+                    }
+                }
+            }
+        }
         // ---------------- box steps ----------------
         // Run until a quarter of the lanes that entered the loop have stopped walking (parked on a leaf or finished
         // their ray): one ballot + popcount per step is the whole scheduling cost.
@@ -260,6 +287,9 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                         walking = pending < 0 && node != end;
                     }
                 } while (__popcll(__ballot(walking)) >= (minWalk > 1 ? minWalk : 1));
+                // (Requesting both successors ahead of the box test was measured and rejected: the L1 is busy ~80 % of
+                //  the launch — TCP_GATE_EN — and doubling its requests cost 7 % in the bulk and gained nothing in the
+                //  drain)
             }
         }
         // ---------------- leaf tests of parked lanes ----------------
@@ -300,8 +330,10 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         // ---------------- shading ----------------
         unsigned long long shadeM = __ballot(state == PS_SHADE);
         if (shadeM != 0ull) {
-            bool canTrace = __ballot(state == PS_TRACE) != 0ull;
-            if (__popcll(shadeM) >= RD_SHADE_MIN || !canTrace) {
+            // Shade once a quarter of the busy lanes wait for it (16 of 64 in the bulk of the frame; in the drain, with a
+            // handful of lanes left, a lane must not wait for every other lane's ray to end before it may continue).
+            int nBusy = __popcll(__ballot(state != PS_IDLE));
+            if (__popcll(shadeM) * 64 >= nBusy * RD_SHADE_MIN) {
                 if (state == PS_SHADE) {
                     v3 rayDir = rs.d;
                     bool terminate = true;  // set false once a shadow or extension ray is started

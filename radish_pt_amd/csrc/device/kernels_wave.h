@@ -200,6 +200,31 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
         }
         const int minAlive = exhausted ? 1 : (64 - RD_REFILL_MIN + 1);
 
+        // ---- literal-class rays: traced whole by the whole wave (traverse.h, coopTraceWhole) ----
+        {
+            unsigned long long lit = __ballot(alive && rs.cls != 0 && node == 0 && pending < 0);
+            while (lit) {
+                const int L = __ffsll((long long)lit) - 1;
+                lit &= lit - 1ull;
+                const bool shadowL = readlaneI(isShadow ? 1 : 0, L) != 0;
+                const NodeRec *un = readlanePtr(nodes, L);
+                const RaySlab ur = readlaneRay(rs, L);
+                const float lim = readlaneF(tmax, L);
+                CoopTrace ct = shadowL ? coopTraceWhole<true>(s, un, ur, lim) : coopTraceWhole<false>(s, un, ur, lim);
+                if (int(threadIdx.x & 63u) == L) {
+                    hitPrim = ct.hitPrim;
+                    hitBary = ct.bary;
+                    tmax = ct.tmax;
+                    occluded = ct.found;
+                    node = end;
+                    alive = false;
+                    if (COUNT) {
+                        ws.nodes += ct.nodes;
+                        ws.tris += ct.tris;
+                    }
+                }
+            }
+        }
         // ---- box steps until enough lanes are parked on a leaf or enough lanes have finished ----
         for (;;) {
             bool walking = alive && pending < 0;

@@ -206,14 +206,146 @@ RD_DEV bool boxTest(float4 lo, float4 hi, const RaySlab &rs, float &t) {
 #define RD_LEAF_DEN 4
 #endif
 
+// ---- wave-cooperative walk of ONE ray ------------------------------------------------------------------------------
+// A lone ray pays ~370 ns per box step (dependent gather + ~65 instructions, measured), and node visits per ray are
+// heavy-tailed, so the last few rays of a launch decide when it ends.  When only a few lanes of a wave are still
+// walking, the whole wave works for one of them: lane j tests node `base + j` of the 64 consecutive records that
+// follow the ray's position (threaded order = memory order, so this is one coalesced 2 KB read), then the walk through
+// that window is resolved with scalar bit operations — runs of inner-node descents are skipped with a find-first-set,
+// a miss follows the record's miss link if it lands inside the window.  Every decision is the per-lane walk's
+// (same box test on the same record against the same tmax), only evaluated ahead of time; nodes that the sequential
+// walk would not visit are tested but not counted.  Returns at the first leaf hit (the triangle test belongs to the
+// owner lane and may change tmax), at the end of the walk, or after `maxWindows` windows.
+// ALL 64 lanes must call this with identical arguments (exec = full wave).
+struct CoopResult {
+    int node, pending;
+    unsigned visited;
+};
+RD_DEV int readlaneI(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+RD_DEV float readlaneF(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+RD_DEV CoopResult coopWalk(const NodeRec *nodes, int node, int end, const RaySlab &u, float tmax, int maxWindows) {
+    const int lane = int(threadIdx.x & 63u);
+    CoopResult r{node, -1, 0u};
+    for (int w = 0; w < maxWindows && r.node != end && r.pending < 0; ++w) {
+        const int base = r.node;
+        const int nvalid = (end - base) < 64 ? (end - base) : 64;
+        const bool valid = lane < nvalid;
+        float4 lo = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), hi = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            lo = nodes[base + lane].lo_prim;
+            hi = nodes[base + lane].hi_next;
+        }
+        float t = 0.f;
+        bool bh;
+        if (u.cls == 0) bh = aabbFast(lo, hi, u, t);  // the ray is wave-uniform here, so this is a scalar branch:
+        else bh = aabbIntersect(mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), u, t);  // the literal test costs nothing extra
+        const unsigned long long D = __ballot(valid && bh && t < tmax);             // would descend
+        const unsigned long long LEAF = __ballot(valid && __float_as_int(lo.w) >= 0);
+        const unsigned long long run = D & ~LEAF;                                  // inner-node descents
+        int cur = 0;
+        for (;;) {
+            unsigned long long rest = ~(run >> cur);
+            int k = rest ? (__ffsll((long long)rest) - 1) : 64;
+            r.visited += (unsigned)k;
+            cur += k;
+            if (cur >= nvalid) {  // walked off the window (or to the end of the array)
+                r.node = base + cur;
+                break;
+            }
+            r.visited += 1u;
+            if ((D >> cur) & 1ull) {  // leaf whose box is hit: park for the triangle test
+                r.pending = readlaneI(__float_as_int(lo.w), cur);
+                r.node = base + cur + 1;
+                break;
+            }
+            int nxt = readlaneI(__float_as_int(hi.w), cur);  // miss link (always > base + cur)
+            if (nxt - base < nvalid) {
+                cur = nxt - base;
+            } else {
+                r.node = nxt;
+                break;
+            }
+        }
+    }
+    return r;
+}
+
+// Broadcast lane L's ray to the whole wave (SGPRs).
+RD_DEV RaySlab readlaneRay(const RaySlab &rs, int L) {
+    RaySlab u;
+    u.o = mk3(readlaneF(rs.o.x, L), readlaneF(rs.o.y, L), readlaneF(rs.o.z, L));
+    u.d = mk3(readlaneF(rs.d.x, L), readlaneF(rs.d.y, L), readlaneF(rs.d.z, L));
+    u.inv = mk3(readlaneF(rs.inv.x, L), readlaneF(rs.inv.y, L), readlaneF(rs.inv.z, L));
+    u.cls = readlaneI(rs.cls, L);
+    return u;
+}
+RD_DEV const NodeRec *readlanePtr(const NodeRec *p, int L) {
+    unsigned long long v = (unsigned long long)p;
+    unsigned lo = (unsigned)readlaneI((int)(unsigned)v, L), hi = (unsigned)readlaneI((int)(unsigned)(v >> 32), L);
+    return (const NodeRec *)(((unsigned long long)hi << 32) | lo);
+}
+
+// A whole trace of ONE ray by the whole wave: coopWalk to the next leaf hit, triangle test, repeat.  This is how rays
+// of the literal classes (a direction component that is axis-parallel, tiny or non-finite) are traced: the
+// reference's box test ignores one slab for them (bvh.h:138-148), so they descend into nearly every box — thousands of
+// steps, at ~0.8 us each through the per-lane literal path, enough for ONE such ray to decide when a launch ends
+// (measured: an 8 ms G-buffer pass on the teapots scene, of which ~5 ms was one ray).  Cooperatively the literal test is
+// a scalar branch, 64 boxes are tested per read, and runs of descents are skipped in one find-first-set.
+// Every lane computes the (uniform) triangle test; all lanes return the same record.
+struct CoopTrace {
+    int hitPrim;
+    v2 bary;
+    float tmax;
+    bool found;
+    unsigned nodes, tris;
+};
+template <bool ANY>
+RD_DEV CoopTrace coopTraceWhole(const DScene &s, const NodeRec *nodes, const RaySlab &u, float tLimit) {
+    CoopTrace o{-1, mk2(0.f, 0.f), tLimit, false, 0u, 0u};
+    const int end = s.bvhSize;
+    int node = 0;
+    while (node != end) {
+        CoopResult r = coopWalk(nodes, node, end, u, o.tmax, 1 << 30);
+        o.nodes += r.visited;
+        node = r.node;
+        if (r.pending >= 0) {
+            TriVerts t = loadTri(s.tris, r.pending);
+            float dist;
+            v2 bary;
+            o.tris++;
+            bool hit = intersectTriangle(u, t.a, t.b, t.c, bary, dist);
+            if (hit && dist < o.tmax) {
+                if (ANY) {
+                    o.found = true;
+                    node = end;
+                } else {
+                    o.hitPrim = r.pending;
+                    o.tmax = dist;
+                    o.bary = bary;
+                }
+            }
+        }
+    }
+    return o;
+}
+
+#ifndef RD_COOP_MAX
+#define RD_COOP_MAX 1      // cooperate once at most this many lanes of the wave are still walking (2-3: measured slower)
+#endif
+#ifndef RD_COOP_WINDOWS
+#define RD_COOP_WINDOWS 8  // windows per lane per turn
+#endif
+
 // One threaded-BVH walk per lane (DevScene::intersect, scene.h:262-301, and DevScene::testOcclusion's loop,
 // :316-333).  Each lane performs exactly the reference's sequence — box test, on a leaf hit the triangle test, strict
 // `<` updates, node++ / nextNodeIfMiss — but the wave runs it "while-while": lanes step through boxes until enough of
 // them are parked on a leaf, then the parked lanes test their triangles together.  Only ~3 % of visits reach a
 // triangle, so testing as soon as ONE lane needs it (the if-if form) makes every step pay for a triangle test.
 // ANY = true: any-hit with a fixed distance bound; returns true on the first accepted triangle.
+// `active` = false lets a lane take part in the wave-level scheduling (and in coopWalk) without tracing anything;
+// call sites that can, call this from uniform control flow with a flag instead of from inside a branch.
 template <bool COUNT, bool ANY>
-RD_DEV bool walkRay(const DScene &s, const Ray &ray, float tLimit, HitRec &h, WalkStats &ws) {
+RD_DEV bool walkRay(const DScene &s, const Ray &ray, float tLimit, HitRec &h, WalkStats &ws, bool active = true) {
     RaySlab rs = makeRaySlab(ray);
     const NodeRec *nodes = s.nodes[getMTBVHId(-ray.d)];
     h.prim = -1;
@@ -222,8 +354,29 @@ RD_DEV bool walkRay(const DScene &s, const Ray &ray, float tLimit, HitRec &h, Wa
     int node = 0;
     const int end = s.bvhSize;
     int pending = -1;
-    bool alive = node != end;
+    bool alive = active && node != end;
     bool found = false;
+    const bool fullWave = __ballot(true) == ~0ull;  // the cooperative routines need every lane of the wave
+    if (fullWave) {
+        // literal-class rays: traced whole, one after the other, by the whole wave (see coopTraceWhole)
+        unsigned long long lit = __ballot(alive && rs.cls != 0);
+        while (lit) {
+            const int L = __ffsll((long long)lit) - 1;
+            lit &= lit - 1ull;
+            CoopTrace ct = coopTraceWhole<ANY>(s, readlanePtr(nodes, L), readlaneRay(rs, L), readlaneF(tLimit, L));
+            if (int(threadIdx.x & 63u) == L) {
+                h.prim = ct.hitPrim;
+                h.bary = ct.bary;
+                h.dist = ct.tmax;
+                found = ct.found;
+                if (COUNT) {
+                    ws.nodes += ct.nodes;
+                    ws.tris += ct.tris;
+                }
+                alive = false;
+            }
+        }
+    }
     for (;;) {
         for (;;) {
             bool walking = alive && pending < 0;
@@ -231,6 +384,25 @@ RD_DEV bool walkRay(const DScene &s, const Ray &ray, float tLimit, HitRec &h, Wa
             if (wm == 0ull) break;
             unsigned long long pm = __ballot(alive && pending >= 0);
             if (__popcll(pm) * RD_LEAF_DEN >= (__popcll(wm) + __popcll(pm)) * RD_LEAF_NUM && pm != 0ull) break;
+            if (fullWave && __popcll(wm) <= RD_COOP_MAX) {
+                // few walkers left: the wave serves them one at a time
+                unsigned long long todo = wm;
+                while (todo) {
+                    const int L = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    {
+                        CoopResult cr = coopWalk(readlanePtr(nodes, L), readlaneI(node, L), end, readlaneRay(rs, L),
+                                                 readlaneF(h.dist, L), RD_COOP_WINDOWS);
+                        if (int(threadIdx.x & 63u) == L) {
+                            node = cr.node;
+                            pending = cr.pending;
+                            if (COUNT) ws.nodes += cr.visited;
+                            alive = (node != end) || pending >= 0;
+                        }
+                    }
+                }
+                continue;
+            }
             if (walking) {
                 float4 lo = nodes[node].lo_prim;
                 float4 hi = nodes[node].hi_next;
@@ -272,15 +444,15 @@ RD_DEV bool walkRay(const DScene &s, const Ray &ray, float tLimit, HitRec &h, Wa
 
 // DevScene::intersect (scene.h:262-301), geometry part.  `prim` = NullPrimitive (-1) on a miss.
 template <bool COUNT>
-RD_DEV HitRec traceClosest(const DScene &s, const Ray &ray, WalkStats &ws) {
+RD_DEV HitRec traceClosest(const DScene &s, const Ray &ray, WalkStats &ws, bool active = true) {
     HitRec h;
-    walkRay<COUNT, false>(s, ray, 3.402823466e+38f /* FLT_MAX */, h, ws);
+    walkRay<COUNT, false>(s, ray, 3.402823466e+38f /* FLT_MAX */, h, ws, active);
     return h;
 }
 
 // DevScene::testOcclusion (scene.h:303-334)
 template <bool COUNT>
-RD_DEV bool traceOccluded(const DScene &s, v3 x, v3 y, WalkStats &ws) {
+RD_DEV bool traceOccluded(const DScene &s, v3 x, v3 y, WalkStats &ws, bool active = true) {
     const float eps = 1e-4f;
     v3 dir = y - x;
     float dist = length(dir);
@@ -288,7 +460,7 @@ RD_DEV bool traceOccluded(const DScene &s, v3 x, v3 y, WalkStats &ws) {
     dist -= eps;
     Ray ray = makeOffsetedRay(x, dir);
     HitRec h;
-    return walkRay<COUNT, true>(s, ray, dist, h, ws);
+    return walkRay<COUNT, true>(s, ray, dist, h, ws, active);
 }
 
 // Wave-level reduction of the per-lane walk statistics, then one atomic per counter per wave.
