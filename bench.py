@@ -7,9 +7,10 @@ renders Sobol row `looper = s` with `iter = 0` (the reference app resets `iterat
 device-resident image buffers.
 
 N = 1:  one process, one GPU, frame layout.
-Frames in flight (default 2): consecutive frames are independent (iter = 0), so frame s+1 is issued on a second HIP
-stream into its own buffers while frame s is still draining its last long paths; every frame is rendered completely and
-ms_per_step = wall time of the K frames / K.  `--frames-in-flight 1` gives the strictly serial figure.
+Frames in flight (default: one per GPU of the job, so 1 at N = 1): consecutive frames are independent (iter = 0), so with
+F > 1 frame s+1 is issued on another HIP stream into its own buffers while frame s is still draining its last long paths
+— with the frame cut N ways each GPU's share of one frame is too small to fill it (a frame's latency is its longest path,
+not its pixel count).  Every frame is rendered completely; ms_per_step = wall time of the K frames / K.
 
 N > 1:  launched by torch.distributed.run, one rank per GPU.  The frame is cut into 64x64 tiles, tile t → rank t % N
         (strong scaling: the frame is fixed, per-GPU work shrinks).  Each rank traces its tiles into packed tile
@@ -60,8 +61,9 @@ def main():
     ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_small", "teapots", "teapots_lights"])
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RADISH_FRAMES_IN_FLIGHT", "2")),
-                    help="frames rendered concurrently, each on its own HIP stream into its own image buffers")
+    ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RADISH_FRAMES_IN_FLIGHT", "0")),
+                    help="frames rendered concurrently, each on its own HIP stream into its own image buffers "
+                         "(0 = one per GPU of the job, at most 8)")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,7 +109,7 @@ def main():
     # One "slot" per frame in flight: its own context (stream, persistent-kernel workspace) and its own image buffers,
     # so consecutive frames are independent (iter = 0: each frame overwrites its images) and can overlap on the GPU —
     # the tail of frame s, where a few long paths are still running, is filled by the start of frame s+1.
-    F = max(1, args.frames_in_flight)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else min(8, max(1, world))
 
     class Slot:
         pass

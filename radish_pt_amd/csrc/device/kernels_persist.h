@@ -268,7 +268,18 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         {
             bool walking = state == PS_TRACE && pending < 0 && node != end;
             int nStart = __popcll(__ballot(walking));
-            if (nStart > 0) {
+            if (nStart == 1) {
+                // a lone walker (the drain of the frame): the whole wave tests 64 boxes ahead for it (coopWalk)
+                const int L = __ffsll((long long)__ballot(walking)) - 1;
+                CoopResult cr = coopWalk(readlanePtr(nodes, L), readlaneI(node, L), end, readlaneRay(rs, L), readlaneF(tmax, L),
+                                         RD_COOP_WINDOWS);
+                if (lane == L) {
+                    node = cr.node;
+                    pending = cr.pending;
+                    pathSteps += cr.visited;
+                    if (COUNT) ws.nodes += cr.visited;
+                }
+            } else if (nStart > 0) {
                 const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
                 do {
                     if (walking) {
