@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "persistent"),
                     choices=["mega", "wavefront", "wavefront_sort", "persistent"])
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_small", "teapots", "teapots_lights"])
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_small", "teapots", "teapots_lights", "teasets_1m"])
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RADISH_FRAMES_IN_FLIGHT", "0")),
@@ -100,7 +100,9 @@ def main():
 
     W, H, depth = args.width, args.height, args.depth
     sd = {"cornell": scenes.cornell, "cornell_small": lambda: scenes.cornell(segments=16, bands=12),
-          "teapots": scenes.teapots, "teapots_lights": lambda: scenes.teapots(emissive_grid=(16, 32))}[args.scene]()
+          "teapots": scenes.teapots, "teapots_lights": lambda: scenes.teapots(emissive_grid=(16, 32)),
+          # stand-in for BASELINE config 5's "camera and tea sets" (asset absent): the teapots scene re-tessellated to ~1.0 M tris
+          "teasets_1m": lambda: scenes.teapots(segments=200, bands=156, emissive_grid=(16, 32))}[args.scene]()
     cam = scenes.cornell_camera(W, H) if args.scene.startswith("cornell") else scenes.teapots_camera(W, H)
     flags = {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
              "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,

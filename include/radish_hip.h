@@ -23,11 +23,14 @@ extern "C" {
 #define RDH_OK 0
 #define RDH_ERR_ARGS (-1)        /* null / inconsistent arguments                         */
 #define RDH_ERR_NO_SCENE (-2)    /* call needs rdh_scene_upload + rdh_set_camera first    */
-#define RDH_ERR_UNSUPPORTED (-3) /* textures / env map: not built yet                     */
+#define RDH_ERR_UNSUPPORTED (-3) /* a combination that is not built (e.g. ReSTIR with world > 1)           */
 #define RDH_ERR_NO_DEVICE (-4)   /* no usable HIP device — there is NO CPU fallback       */
 #define RDH_ERR_STATE (-5)       /* e.g. rdh_restir_direct before rdh_restir_init         */
 
 typedef struct rdh_ctx rdh_ctx;
+
+/* One texture: DevTextureObj (src/image.h:89-91) with a HOST pointer; texels are glm::vec3, row-major (Image::data()). */
+typedef struct rdh_texture { int32_t width, height; const float *data; } rdh_texture;
 
 /* Host arrays in the reference's DevScene layout (src/scene.h:494-517).
  * Replaces the argument of DevScene::create(const Scene&) (src/scene.cpp:461-551). */
@@ -49,6 +52,14 @@ typedef struct rdh_scene_desc {
     int32_t lightSamplerLength;       /* DevDiscreteSampler1D::length (== numLights without an env map)        */
     const void *lightSampler;         /* BinomialDistrib<float>[length] = {float prob; int failId}             */
     const uint32_t *sampleSequence;   /* uint32[10000][200] Sobol table (src/scene.cpp:543-548)                */
+    /* Textures and environment map (src/scene.cpp:463-486, 529-532).  Material map ids index `textures`
+     * (-1 = NullTextureId, -2 = ProceduralTexId for baseColorMapId only). */
+    int32_t numTextures;
+    const struct rdh_texture *textures;
+    int32_t envMapTexId;              /* Scene::envMapTexId: -1 = no environment map                           */
+    int32_t envMapSamplerLength;      /* envMapSampler.length = width*height of the env map, 0 = none;
+                                         with an env map the LAST lightSampler entry is the env map (scene.cpp:163) */
+    const void *envMapSampler;        /* BinomialDistrib<float>[envMapSamplerLength]                           */
 } rdh_scene_desc;
 
 /* Byte-for-byte the reference's GBuffer (src/gBuffer.h:42-57, 272 B) with DENOISER_ENCODE_NORMAL=false,

@@ -30,6 +30,11 @@ int32_t rdh_build_light_list(const float *vertices, const int32_t *materialIds, 
                              const void *materials, int32_t numMaterials, int32_t *lightPrimIdsOut,
                              float *lightUnitRadianceOut, float *lightPowerOut);
 
+/* Replaces the environment-map half of Scene::createLightSampler (src/scene.cpp:146-157):
+ * pdfOut[i*width+j] = luminance(texel) * sin((0.5 + i) / height * PI).  Feed pdfOut to rdh_build_alias_table to get
+ * the env-map sampler; its sum is the power entry appended LAST to the light-power list (src/scene.cpp:163). */
+int32_t rdh_build_envmap_pdf(const float *texels, int32_t width, int32_t height, float *pdfOut);
+
 /* Replaces Camera::update (src/sceneStructs.h:93-107) plus the fov bookkeeping of Scene::loadCamera
  * (src/scene.cpp:378-383).  camera196 in/out: resolution, position, rotation, fov.y (degrees, "FovY"),
  * lensRadius, focalDist must be set; view/up/right/rotationMatInv/fov.x/tanFovY/viewProjection are written. */

@@ -133,6 +133,16 @@ inline vec2 concentricSampleDisk(float x, float y) {  // :132-136
     sincos_det(theta, &s, &c);
     return vec2(r * c, r * s);
 }
+inline vec3 toSphere(vec2 v) {  // :138-142
+    v = v * vec2(TWO_PI_F, PI_F);
+    float sx, cx, sy, cy;
+    sincos_det(v.x, &sx, &cx);
+    sincos_det(v.y, &sy, &cy);
+    return vec3(cx * sy, cy, sx * sy);
+}
+inline vec2 toPlane(vec3 v) {  // :143-147 (Blinn–Newell); `x * INV_PI * 0.5f` parses as ((x * 1.f) / PI) * 0.5f
+    return vec2(fract(atan2_det(v.z, v.x) / PI_F * 0.5f + 1.f), atan2_det(length(vec2(v.x, v.z)), v.y) / PI_F);
+}
 inline mat3 localRefMatrix(vec3 n) {  // :149-155
     vec3 t = (fabsf(n.y) > 0.9999f) ? vec3(0.f, 0.f, 1.f) : vec3(0.f, 1.f, 0.f);
     vec3 b = normalize(cross(n, t));
@@ -449,6 +459,49 @@ inline vec2 cameraRasterUV(const Camera &c, vec3 pos) {  // :22-43
 // ------------------------------------------------------------------------------------------------
 // DevScene — src/scene.h:73-518
 // ------------------------------------------------------------------------------------------------
+// linearSample — src/image.h:42-87 (wrap-around bilinear)
+inline vec3 linearSample(const vec3 *data, vec2 uv, int width, int height) {
+    const float eps = FLT_MIN;
+    uv = fract(uv);
+    float fx = uv.x * (float(width) - eps) + 0.5f;
+    float fy = uv.y * (float(height) - eps) + 0.5f;
+    int ix = int(fract(fx) > 0.5f ? fx : fx - 1.f);
+    int iy = int(fract(fy) > 0.5f ? fy : fy - 1.f);
+    if (ix < 0) ix += width;
+    if (iy < 0) iy += height;
+    int ux = ix + 1;
+    int uy = iy + 1;
+    if (ux >= width) ux -= width;
+    if (uy >= height) uy -= height;
+    float lx = fract(fx + 0.5f);
+    float ly = fract(fy + 0.5f);
+    vec3 c1 = mix(data[iy * width + ix], data[iy * width + ux], lx);
+    vec3 c2 = mix(data[uy * width + ix], data[uy * width + ux], lx);
+    return mix(c1, c2, ly);
+}
+// proceduralTexture — src/scene.h:77-86.  thrust::default_random_engine is minstd_rand (x' = 48271 x mod 2^31-1,
+// seed 0 → 1) and thrust::uniform_real_distribution<float> maps a draw u to float(u - 1) / (1.f + float(2^31 - 3))
+// (thrust 1.15 / CUDA 11.7, thrust/random/detail/{linear_congruential_engine,uniform_real_distribution}.inl — not
+// under /root/reference; restated from the published source, parity unpinned).
+inline float minstdUniform(uint32_t &x) {
+    x = uint32_t((uint64_t(x) * 48271ull) % 2147483647ull);
+    return float(x - 1u) / (1.f + float(2147483646u - 1u));
+}
+inline vec3 proceduralTexture(vec2 uv) {
+    uint32_t seed = uint32_t(int(uv.x * 1024) * 1024 + int(uv.y * 1024));
+    uint32_t x = seed % 2147483647u;
+    if (x == 0u) x = 1u;
+    float rx = minstdUniform(x);
+    float ry = minstdUniform(x);
+    float s0, c0, s1, c1;
+    sincos_det(uv.x * 10.f * TWO_PI_F + rx * TWO_PI_F, &s0, &c0);
+    sincos_det(uv.y * 10.f * TWO_PI_F + ry * TWO_PI_F, &s1, &c1);
+    float f = (s0 + +1.f) * .5f;
+    float g = (s1 + +1.f) * .5f;
+    return vec3(f * g);
+}
+constexpr int ProceduralTexId = -2;  // src/material.h:15
+
 struct SceneView {
     orc_scene *h;
     const orc_scene_desc &d() const { return h->d; }
@@ -458,9 +511,52 @@ struct SceneView {
     const AABB *boxes() const { return (const AABB *)h->d.boundingBoxes; }
     const Material *materials() const { return (const Material *)h->d.materials; }
 
+    vec3 texSample(int id, vec2 uv) const {  // DevTextureObj::linearSample (image.h:82-84)
+        const orc_texture &t = d().textures[id];
+        return linearSample((const vec3 *)t.data, uv, t.width, t.height);
+    }
+    bool hasEnvMap() const { return d().envMapTexId >= 0; }
     Material getTexturedMaterialAndSurface(Intersection &intersec) const {  // scene.h:88-112
-        // Texture ids other than NullTextureId are rejected at scene creation (round-1 scope).
-        return materials()[intersec.matId];
+        Material mat = materials()[intersec.matId];
+        if (mat.baseColorMapId != NullTextureId) {
+            mat.baseColor = mat.baseColorMapId == ProceduralTexId ? proceduralTexture(intersec.uv)
+                                                                  : texSample(mat.baseColorMapId, intersec.uv);
+        }
+        if (mat.metallicMapId > NullTextureId) mat.metallic = texSample(mat.metallicMapId, intersec.uv).x;
+        if (mat.roughnessMapId > NullTextureId) mat.roughness = texSample(mat.roughnessMapId, intersec.uv).x;
+        if (mat.normalMapId != NullTextureId) {
+            vec3 mapped = texSample(mat.normalMapId, intersec.uv);
+            vec3 localNorm = normalize(vec3(mapped.x, mapped.y, mapped.z) * 1.f - 0.5f);  // sic
+            intersec.norm = localToWorld(intersec.norm, localNorm);
+        }
+        return mat;
+    }
+    int envSample(float r1, float r2) const {  // envMapSampler.sample (sampler.h:204-208)
+        const BinomialDistrib *t = (const BinomialDistrib *)d().envMapSampler;
+        int length = d().envMapSamplerLength;
+        int passId = gmin(int(float(length) * r1), length - 1);
+        BinomialDistrib distrib = t[passId];
+        return (r2 < distrib.prob) ? passId : distrib.failId;
+    }
+    vec3 envLookup(vec3 dir) const { return texSample(d().envMapTexId, toPlane(dir)); }
+    float environmentMapPdf(vec3 wi) const {  // scene.h:374-378
+        const orc_texture &e = d().textures[d().envMapTexId];
+        vec3 radiance = envLookup(wi);
+        return luminance(radiance) * d().sumLightPowerInv * e.width * e.height * 0.5f;
+    }
+    // sampleEnvironmentMap / sampleEnvMapNoVisbility (scene.h:380-414); visibility = false skips the occlusion test
+    float sampleEnvironmentMap(vec3 pos, vec2 r, vec3 &radiance, vec3 &wi, bool visibility) const {
+        const orc_texture &e = d().textures[d().envMapTexId];
+        int pixId = envSample(r.x, r.y);
+        int y = pixId / e.width;
+        int x = pixId - y * e.width;
+        radiance = ((const vec3 *)e.data)[pixId];
+        wi = toSphere(vec2((x + 0.5f) / e.width, (y + 0.5f) / e.height));
+        if (visibility) {
+            bool occ = testOcclusion(pos, pos + wi * 1e6f);
+            if (occ) return INVALID_PDF;
+        }
+        return luminance(radiance) * d().sumLightPowerInv * e.width * e.height / PI_F / PI_F * 0.5f;
     }
     static int getMTBVHId(vec3 dir) {  // scene.h:114-129
         vec3 absDir = gabs(dir);
@@ -597,10 +693,12 @@ struct SceneView {
         BinomialDistrib distrib = t[passId];
         return (r2 < distrib.prob) ? passId : distrib.failId;
     }
-    // scene.h:419-456.  Env-map branch (:426-428) is unreachable: envMapSampler.length == 0 in round 1.
+    // scene.h:419-456
     float sampleDirectLight(vec3 pos, vec4 r, vec3 &radiance, vec3 &wi) const {
         if (d().lightSamplerLength == 0) return INVALID_PDF;
         int lightId = lightSample(r.x, r.y);
+        if (lightId == d().lightSamplerLength - 1 && d().envMapSamplerLength != 0)
+            return sampleEnvironmentMap(pos, vec2(r.z, r.w), radiance, wi, true);
         int primId = d().lightPrimIds[lightId];
         vec3 v0 = vertices()[primId * 3 + 0], v1 = vertices()[primId * 3 + 1], v2 = vertices()[primId * 3 + 2];
         vec3 sampled = sampleTriangleUniform(v0, v1, v2, r.z, r.w);
@@ -619,6 +717,10 @@ struct SceneView {
     float sampleDirectLightNoVisibility(vec3 pos, vec4 r, vec3 &radiance, vec3 &wi, float &dist) const {
         if (d().lightSamplerLength == 0) return INVALID_PDF;
         int lightId = lightSample(r.x, r.y);
+        if (lightId == d().lightSamplerLength - 1 && d().envMapSamplerLength != 0) {
+            dist = 1e10f;
+            return sampleEnvironmentMap(pos, vec2(r.z, r.w), radiance, wi, false);
+        }
         int primId = d().lightPrimIds[lightId];
         vec3 v0 = vertices()[primId * 3 + 0], v1 = vertices()[primId * 3 + 1], v2 = vertices()[primId * 3 + 2];
         vec3 sampled = sampleTriangleUniform(v0, v1, v2, r.z, r.w);
@@ -687,7 +789,14 @@ void pathTracePixel(const SceneView &scene, const Camera &cam, float tanFovY, in
             vec3 curPos = intersec.pos;
             scene.intersect(ray, intersec);
             intersec.wo = -ray.direction;
-            if (intersec.primId == NullPrimitive) break;  // env map absent (:232-247)
+            if (intersec.primId == NullPrimitive) {  // :232-247
+                if (scene.hasEnvMap()) {
+                    vec3 radiance = scene.envLookup(ray.direction) * throughput;
+                    float weight = deltaSample ? 1.f : powerHeuristic(sample.pdf, scene.environmentMapPdf(ray.direction));
+                    indirect += radiance * weight;
+                }
+                break;
+            }
             material = scene.getTexturedMaterialAndSurface(intersec);
             if (material.type == Light) {
                 if (dot(intersec.norm, ray.direction) < 0.f) break;  // SCENE_LIGHT_SINGLE_SIDED (:252-256)
@@ -721,7 +830,10 @@ void pathTraceDirectPixel(const SceneView &scene, const Camera &cam, float tanFo
     Intersection intersec;
     scene.intersect(ray, intersec);
     do {
-        if (intersec.primId == NullPrimitive) break;  // no env map
+        if (intersec.primId == NullPrimitive) {  // :309-314
+            if (scene.hasEnvMap()) direct = scene.envLookup(ray.direction);
+            break;
+        }
         Material material = scene.getTexturedMaterialAndSurface(intersec);
         if (material.type == Light) {
             direct = material.baseColor;
@@ -777,7 +889,7 @@ void gbufferPixel(const SceneView &scene, const Camera &cam, const Camera &lastC
         if (lx >= 0 && lx < gb->width && ly >= 0 && ly < gb->height) gb->motion[idx] = ly * cam.resx + lx;
         else gb->motion[idx] = -1;
     } else {
-        albedo[idx] = vec3(0.f);
+        albedo[idx] = scene.hasEnvMap() ? scene.envLookup(ray.direction) : vec3(0.f);  // gBuffer.cu:61-66
         normal[idx] = vec3(0.f);
         gb->primId[cur][idx] = NullPrimitive;
         gb->depth[cur][idx] = 1.f;
@@ -882,10 +994,11 @@ extern "C" {
 orc_scene *orc_scene_create(const orc_scene_desc *desc) {
     const Material *m = (const Material *)desc->materials;
     for (int i = 0; i < desc->numMaterials; i++) {
-        if (m[i].baseColorMapId != NullTextureId || m[i].normalMapId != NullTextureId ||
-            m[i].metallicMapId > NullTextureId || m[i].roughnessMapId > NullTextureId)
-            return nullptr;  // textures: out of round-1 scope
+        int ids[4] = {m[i].baseColorMapId, m[i].normalMapId, m[i].metallicMapId, m[i].roughnessMapId};
+        for (int k = 0; k < 4; k++)
+            if (ids[k] >= desc->numTextures || ids[k] < -2 || (ids[k] == -2 && k != 0)) return nullptr;
     }
+    if (desc->envMapTexId >= desc->numTextures) return nullptr;
     orc_scene *s = new orc_scene;
     s->d = *desc;
     memset(&s->st, 0, sizeof(s->st));
@@ -977,7 +1090,10 @@ void orc_restir_direct(orc_scene *s, const void *camera196, float *directIllum, 
             Ray ray = cameraSample(cam, tanFovY, x, y, sample4D(rng));
             Intersection &intersec = ps.intersec;
             scene.intersect(ray, intersec);
-            if (intersec.primId == NullPrimitive) continue;  // no env map: direct stays 0 (:117-122)
+            if (intersec.primId == NullPrimitive) {  // :117-122
+                if (scene.hasEnvMap()) ps.direct = scene.envLookup(ray.direction);
+                continue;
+            }
             Material &material = ps.material;
             material = scene.getTexturedMaterialAndSurface(intersec);
             material.baseColor = vec3(1.f);  // :125
@@ -1067,6 +1183,12 @@ int orc_intersect_triangle(const float *r, const float *v, float *bary2, float *
     return hit ? 1 : 0;
 }
 void orc_sincos(float x, float *s, float *c) { sincos_det(x, s, c); }
+float orc_atan2(float y, float x) { return atan2_det(y, x); }
+void orc_texture_sample(orc_scene *s, int texId, const float *uv2, float *rgb3) {
+    SceneView sv{s};
+    vec3 c = texId == ProceduralTexId ? proceduralTexture(vec2(uv2[0], uv2[1])) : sv.texSample(texId, vec2(uv2[0], uv2[1]));
+    rgb3[0] = c.x; rgb3[1] = c.y; rgb3[2] = c.z;
+}
 void orc_material_eval(const void *material44, int which, const float *n3, const float *wo3, const float *w3,
                        float *out8) {
     Material m;

@@ -19,6 +19,8 @@
 extern "C" {
 #endif
 
+typedef struct orc_texture { int32_t width, height; const float *data; /* vec3[width*height] */ } orc_texture;
+
 /* Host arrays in the reference's DevScene layout (src/scene.h:494-517). */
 typedef struct orc_scene_desc {
     const float *vertices;      /* vec3[3*numPrims]  (triangle soup)            */
@@ -38,6 +40,12 @@ typedef struct orc_scene_desc {
     int32_t lightSamplerLength;     /* alias table length (== numLights, no env map) */
     const void *lightSampler;       /* BinomialDistrib<float>[len] = {float prob; int failId} */
     const uint32_t *sobol;          /* uint32[10000][200]                        */
+    /* textures (src/image.h:89-91 DevTextureObj, host pointers) and the environment map (src/scene.h:511-512) */
+    int32_t numTextures;
+    const struct orc_texture *textures;
+    int32_t envMapTexId;            /* -1 = none; else index into textures               */
+    int32_t envMapSamplerLength;    /* width*height of the env map, 0 = none             */
+    const void *envMapSampler;      /* BinomialDistrib<float>[envMapSamplerLength]       */
 } orc_scene_desc;
 
 /* G-buffer in the reference's field order (src/gBuffer.h:42-57), host pointers. */
@@ -97,6 +105,9 @@ uint32_t orc_utilhash(uint32_t a);
 int orc_aabb_intersect(const float *box6, const float *ray6, float *tMin);
 int orc_intersect_triangle(const float *ray6, const float *v9, float *bary2, float *dist);
 void orc_sincos(float x, float *s, float *c);
+float orc_atan2(float y, float x);
+/* linearSample (src/image.h:42-87) of texture `texId` at uv; texId = -2 evaluates proceduralTexture (scene.h:77-86). */
+void orc_texture_sample(orc_scene *s, int texId, const float *uv2, float *rgb3);
 /* BSDF hooks: material44 = 44-byte Material; which: 0 BSDF (out[0..2]), 1 pdf (out[0]),
  * 2 sample (r3 -> out = dir.xyz, bsdf.xyz, pdf, type as float bits). */
 void orc_material_eval(const void *material44, int which, const float *n3, const float *wo3, const float *wi_or_r3,

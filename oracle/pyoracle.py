@@ -21,7 +21,13 @@ class SceneDesc(C.Structure):
         ("numLights", C.c_int32), ("lightPrimIds", C.c_void_p), ("lightUnitRadiance", C.c_void_p),
         ("sumLightPowerInv", C.c_float), ("lightSamplerLength", C.c_int32), ("lightSampler", C.c_void_p),
         ("sobol", C.c_void_p),
+        ("numTextures", C.c_int32), ("textures", C.c_void_p), ("envMapTexId", C.c_int32),
+        ("envMapSamplerLength", C.c_int32), ("envMapSampler", C.c_void_p),
     ]
+
+
+class TextureC(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("data", C.c_void_p)]
 
 
 class GBufferC(C.Structure):
@@ -67,6 +73,10 @@ def lib():
         l.orc_intersect_triangle.restype = i32
         l.orc_intersect_triangle.argtypes = [vp, vp, vp, C.POINTER(f32)]
         l.orc_sincos.argtypes = [f32, C.POINTER(f32), C.POINTER(f32)]
+        l.orc_atan2.restype = f32
+        l.orc_atan2.argtypes = [f32, f32]
+        l.orc_texture_sample.restype = None
+        l.orc_texture_sample.argtypes = [vp, i32, vp, vp]
         l.orc_material_eval.argtypes = [vp, i32, vp, vp, vp, vp]
         l.orc_camera_sample.argtypes = [vp, i32, i32, vp, vp]
         for fn in ("orc_scene_destroy", "orc_stats_reset", "orc_stats_get", "orc_trace_closest", "orc_trace_closest_naive",
@@ -127,6 +137,16 @@ class OracleScene:
         d.lightSamplerLength = len(sd.light_sampler)
         d.lightSampler = sd.light_sampler.ctypes.data
         d.sobol = sd.sobol.ctypes.data
+        texs = getattr(sd, "textures", [])
+        self._tex = (TextureC * max(len(texs), 1))()
+        for i, t in enumerate(texs):
+            self._tex[i].width, self._tex[i].height, self._tex[i].data = t.shape[1], t.shape[0], t.ctypes.data
+        d.numTextures = len(texs)
+        d.textures = C.cast(self._tex, C.c_void_p)
+        d.envMapTexId = getattr(sd, "env_map_tex_id", -1)
+        env = getattr(sd, "env_map_sampler", None)
+        d.envMapSamplerLength = 0 if env is None else len(env)
+        d.envMapSampler = None if env is None or len(env) == 0 else env.ctypes.data
         self._desc = d
         self.h = lib().orc_scene_create(C.byref(d))
         if not self.h:

@@ -49,7 +49,13 @@ class SceneDescC(C.Structure):
         ("numLights", C.c_int32), ("lightPrimIds", C.c_void_p), ("lightUnitRadiance", C.c_void_p),
         ("sumLightPowerInv", C.c_float), ("lightSamplerLength", C.c_int32), ("lightSampler", C.c_void_p),
         ("sampleSequence", C.c_void_p),
+        ("numTextures", C.c_int32), ("textures", C.c_void_p), ("envMapTexId", C.c_int32),
+        ("envMapSamplerLength", C.c_int32), ("envMapSampler", C.c_void_p),
     ]
+
+
+class TextureC(C.Structure):  # rdh_texture
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("data", C.c_void_p)]
 
 
 class GBufferC(C.Structure):  # == the reference's GBuffer, 272 bytes
@@ -180,6 +186,16 @@ class Context:
         d.lightSamplerLength = len(sd.light_sampler)
         d.lightSampler = sd.light_sampler.ctypes.data
         d.sampleSequence = sd.sobol.ctypes.data
+        texs = getattr(sd, "textures", [])
+        tex_c = (TextureC * max(len(texs), 1))()
+        for i, t in enumerate(texs):
+            tex_c[i].width, tex_c[i].height, tex_c[i].data = t.shape[1], t.shape[0], t.ctypes.data
+        d.numTextures = len(texs)
+        d.textures = C.cast(tex_c, C.c_void_p)
+        d.envMapTexId = getattr(sd, "env_map_tex_id", -1)
+        env = getattr(sd, "env_map_sampler", None)
+        d.envMapSamplerLength = 0 if env is None else len(env)
+        d.envMapSampler = None if env is None or len(env) == 0 else env.ctypes.data
         self.check(lib().rdh_scene_upload(self.h, C.byref(d)))
 
     def set_camera(self, cam):

@@ -126,9 +126,66 @@ struct Material {
     v3 baseColor;
     float metallic, roughness, ior;
 };
+// The untextured record (scene->materials[id], e.g. gBuffer.cu:33-34).
 RD_DEV Material loadMaterial(const MatRec *mats, int id) {
     float4 a = mats[id].a, b = mats[id].b;
     return Material{__float_as_int(a.x), mk3(a.y, a.z, a.w), b.x, b.y, b.z};
+}
+
+// ---- textures: image.h:42-87, scene.h:77-112; env map mapping: mathUtil.h:138-147 ----
+RD_DEV v3 toSphere(v2 v) {  // mathUtil.h:138-142
+    v = v * mk2(TWO_PI_F, PI_F);
+    float sx, cx, sy, cy;
+    sincos_det(v.x, sx, cx);
+    sincos_det(v.y, sy, cy);
+    return mk3(cx * sy, cy, sx * sy);
+}
+RD_DEV v2 toPlane(v3 v) {  // mathUtil.h:143-147; `x * INV_PI * 0.5f` == ((x * 1.f) / PI) * 0.5f
+    float len = __builtin_sqrtf(dot(mk2(v.x, v.z), mk2(v.x, v.z)));
+    return mk2(fract_(atan2_det(v.z, v.x) / PI_F * 0.5f + 1.f), atan2_det(len, v.y) / PI_F);
+}
+RD_DEV v3 texel(const float *data, int i) { return mk3(data[3 * i], data[3 * i + 1], data[3 * i + 2]); }
+// linearSample (image.h:42-87): wrap-around bilinear
+RD_DEV v3 linearSample(const float *data, v2 uv, int width, int height) {
+    const float eps = 1.17549435e-38f;  // FLT_MIN
+    uv = mk2(fract_(uv.x), fract_(uv.y));
+    float fx = uv.x * (float(width) - eps) + 0.5f;
+    float fy = uv.y * (float(height) - eps) + 0.5f;
+    int ix = int(fract_(fx) > 0.5f ? fx : fx - 1.f);
+    int iy = int(fract_(fy) > 0.5f ? fy : fy - 1.f);
+    if (ix < 0) ix += width;
+    if (iy < 0) iy += height;
+    int ux = ix + 1;
+    int uy = iy + 1;
+    if (ux >= width) ux -= width;
+    if (uy >= height) uy -= height;
+    float lx = fract_(fx + 0.5f);
+    float ly = fract_(fy + 0.5f);
+    v3 c1 = mix(texel(data, iy * width + ix), texel(data, iy * width + ux), lx);
+    v3 c2 = mix(texel(data, uy * width + ix), texel(data, uy * width + ux), lx);
+    return mix(c1, c2, ly);
+}
+RD_DEV v3 texSample(const DScene &s, int id, v2 uv) {  // DevTextureObj::linearSample
+    int4 ti = s.texInfo[id];
+    return linearSample(s.texData + 3 * (long long)ti.z, uv, ti.x, ti.y);
+}
+// proceduralTexture (scene.h:77-86): minstd_rand + thrust's uniform_real_distribution<float>, restated (see oracle.cpp)
+RD_DEV float minstdUniform(uint32_t &x) {
+    x = uint32_t(((unsigned long long)x * 48271ull) % 2147483647ull);
+    return float(x - 1u) / (1.f + float(2147483646u - 1u));
+}
+RD_DEV v3 proceduralTexture(v2 uv) {
+    uint32_t seed = uint32_t(int(uv.x * 1024) * 1024 + int(uv.y * 1024));
+    uint32_t x = seed % 2147483647u;
+    if (x == 0u) x = 1u;
+    float rx = minstdUniform(x);
+    float ry = minstdUniform(x);
+    float s0, c0, s1, c1;
+    sincos_det(uv.x * 10.f * TWO_PI_F + rx * TWO_PI_F, s0, c0);
+    sincos_det(uv.y * 10.f * TWO_PI_F + ry * TWO_PI_F, s1, c1);
+    float f = (s0 + +1.f) * .5f;
+    float g = (s1 + +1.f) * .5f;
+    return mk3(f * g);
 }
 struct BSDFSample {  // material.h:28-33
     v3 dir, bsdf;

@@ -349,14 +349,21 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                     v3 rayDir = rs.d;
                     bool terminate = true;  // set false once a shadow or extension ray is started
                     do {
-                        if (hitPrim == -1) {  // miss (pathtrace.cu:169-172 primary; :232-247 later, no env map)
-                            if (k == 0) sAccD[0][t] = sAccD[1][t] = sAccD[2][t] = 1.f;
+                        if (hitPrim == -1) {  // miss: pathtrace.cu:169-172 (primary), :232-247 (later)
+                            if (k == 0) {
+                                sAccD[0][t] = sAccD[1][t] = sAccD[2][t] = 1.f;
+                            } else if (hasEnvMap(s)) {
+                                v3 radiance = envLookup(s, rayDir) * mk3(sThr[0][t], sThr[1][t], sThr[2][t]);
+                                float weight = (sFlags[t] & 2) ? 1.f : powerHeuristic(sExtPdf[t], environmentMapPdf(s, rayDir));
+                                v3 add = radiance * weight;
+                                sAccI[0][t] += add.x; sAccI[1][t] += add.y; sAccI[2][t] += add.z;
+                            }
                             break;
                         }
                         nHits++;
                         Surface isec;
                         fetchSurface(s, hitPrim, hitBary, isec);
-                        Material material = loadMaterial(s.mats, isec.matId);
+                        Material material = texturedMaterial(s, isec);
                         v3 throughput;
                         if (k == 0) {
                             material.baseColor = mk3(1.f);  // DENOISER_DEMODULATE (:175-178)
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                         if (!deltaBSDF) {  // NEE (:195-208)
                             v4 r4 = sample4D(rng);
                             if (s.lightSamplerLength != 0) {
-                                LightPick lp = pickLightPoint(s, r4);
+                                LightPick lp = pickLightPoint(s, isec.pos, r4);
                                 v3 radiance = mk3(0.f), wi = mk3(0.f);
                                 float lightPdf = lightPdfUnoccluded(s, isec.pos, lp, radiance, wi);
                                 v3 cc = mk3(0.f);

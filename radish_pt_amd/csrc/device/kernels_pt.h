@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_path_trace_mega(DScene s, DCamera cam, 
             nHits++;
             Surface isec;
             fetchSurface(s, h.prim, h.bary, isec);
-            Material material = loadMaterial(s.mats, isec.matId);
+            Material material = texturedMaterial(s, isec);
             material.baseColor = mk3(1.f);  // DENOISER_DEMODULATE (:175-178)
             if (material.type == Light) {
                 direct = mk3(1.f);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_path_trace_mega(DScene s, DCamera cam, 
                     float lightPdf = INVALID_PDF;
                     v3 radiance = mk3(0.f), wi = mk3(0.f);
                     if (s.lightSamplerLength != 0) {  // sampleDirectLight (scene.h:419-456)
-                        LightPick lp = pickLightPoint(s, r4);
+                        LightPick lp = pickLightPoint(s, isec.pos, r4);
                         nAny++;
                         bool occ = traceOccluded<COUNT>(s, isec.pos, lp.sampled, ws);
                         if (!occ) lightPdf = lightPdfUnoccluded(s, isec.pos, lp, radiance, wi);
@@ -165,11 +165,18 @@ __global__ __launch_bounds__(256) void k_path_trace_mega(DScene s, DCamera cam, 
                 v3 curPos = isec.pos;
                 h = traceClosest<COUNT>(s, ray, ws);
                 nClosest++;
-                if (h.prim == -1) break;  // no env map (:232-247)
+                if (h.prim == -1) {  // :232-247
+                    if (hasEnvMap(s)) {
+                        v3 radiance = envLookup(s, ray.d) * throughput;
+                        float weight = deltaSample ? 1.f : powerHeuristic(sample.pdf, environmentMapPdf(s, ray.d));
+                        indirect = indirect + radiance * weight;
+                    }
+                    break;
+                }
                 nHits++;
                 fetchSurface(s, h.prim, h.bary, isec);
                 isec.wo = -ray.d;
-                material = loadMaterial(s.mats, isec.matId);
+                material = texturedMaterial(s, isec);
                 if (material.type == Light) {
                     if (dot(isec.norm, ray.d) < 0.f) break;  // SCENE_LIGHT_SINGLE_SIDED (:252-256)
                     v3 radiance = material.baseColor;
@@ -212,11 +219,14 @@ __global__ __launch_bounds__(256) void k_path_trace_direct(DScene s, DCamera cam
         HitRec h = traceClosest<COUNT>(s, ray, ws);
         nClosest++;
         do {
-            if (h.prim == -1) break;  // no env map (:307-312)
+            if (h.prim == -1) {  // :307-312
+                if (hasEnvMap(s)) direct = envLookup(s, ray.d);
+                break;
+            }
             nHits++;
             Surface isec;
             fetchSurface(s, h.prim, h.bary, isec);
-            Material material = loadMaterial(s.mats, isec.matId);
+            Material material = texturedMaterial(s, isec);
             if (material.type == Light) {
                 direct = material.baseColor;
                 break;
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(256) void k_path_trace_direct(DScene s, DCamera cam
                 float lightPdf = INVALID_PDF;
                 v3 Li = mk3(0.f), wi = mk3(0.f);
                 if (s.lightSamplerLength != 0) {
-                    LightPick lp = pickLightPoint(s, r4);
+                    LightPick lp = pickLightPoint(s, isec.pos, r4);
                     nAny++;
                     bool occ = traceOccluded<COUNT>(s, isec.pos, lp.sampled, ws);
                     if (!occ) lightPdf = lightPdfUnoccluded(s, isec.pos, lp, Li, wi);
@@ -280,9 +290,9 @@ __global__ __launch_bounds__(256) void k_gbuffer(DScene s, DCamera cam, DCamera 
             nHits++;
             Surface isec;
             fetchSurface(s, h.prim, h.bary, isec);
-            Material material = loadMaterial(s.mats, isec.matId);
             int matId = isec.matId;
-            if (material.type == Light) matId = -2;  // NullPrimitive - 1 (:36-37)
+            if (loadMaterial(s.mats, isec.matId).type == Light) matId = -2;  // NullPrimitive - 1 (:33-37, untextured record)
+            Material material = texturedMaterial(s, isec);            // :44 (may perturb isec.norm)
             store3(gb.albedo, idx, material.baseColor);
             store3(gb.normal, idx, isec.norm);
             gb.primId[idx] = matId;
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(256) void k_gbuffer(DScene s, DCamera cam, DCamera 
             int lx = (int)(float(lastCam.resx) * ndc.x), ly = (int)(float(lastCam.resy) * ndc.y);
             gb.motion[idx] = (lx >= 0 && lx < gb.width && ly >= 0 && ly < gb.height) ? ly * cam.resx + lx : -1;
         } else {
-            store3(gb.albedo, idx, mk3(0.f));
+            store3(gb.albedo, idx, hasEnvMap(s) ? envLookup(s, ray.d) : mk3(0.f));  // :61-66
             store3(gb.normal, idx, mk3(0.f));
             gb.primId[idx] = -1;
             gb.depth[idx] = 1.f;

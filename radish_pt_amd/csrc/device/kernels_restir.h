@@ -116,12 +116,17 @@ RD_DEV Reservoir findSpatialNeighborDisk(const RestirArgs &a, int x, int y, v2 r
 }
 
 // Shade + write (restir.cu:189-202).  `status`: >= 0 shade with this material id; -1 miss; -2 emitter.
+// `missDirect`: what a primary miss leaves in `direct` (the env map sample, restir.cu:117-122); `metallic`/`roughness`:
+// the textured values pass 1 shaded with (the reference keeps the whole Material in registers across its barrier).
 RD_DEV void restirFinish(const DScene &s, const RestirArgs &a, int idx, int status, v3 norm, v3 wo, Reservoir reservoir,
-                         Sampler &rng, int x, int y, bool doSpatial, float *directIllum, int iter) {
-    v3 direct = (status == -2) ? mk3(1.f) : mk3(0.f);
+                         Sampler &rng, int x, int y, bool doSpatial, float *directIllum, int iter, v3 missDirect,
+                         float metallic, float roughness) {
+    v3 direct = (status == -2) ? mk3(1.f) : missDirect;
     if (status >= 0) {
         Material material = loadMaterial(s.mats, status);
         material.baseColor = mk3(1.f);
+        material.metallic = metallic;
+        material.roughness = roughness;
         if (doSpatial) {
             Reservoir resvr = emptyReservoir();  // mergeSpatialNeighborDirect (:82-95)
             for (int i = 0; i < a.numSpatial; i++) {
@@ -165,11 +170,16 @@ __global__ __launch_bounds__(256) void k_restir_pass1(DScene s, DCamera cam, Pix
         isec.norm = mk3(0.f);
         isec.wo = mk3(0.f);
         Reservoir reservoir = emptyReservoir();
+        v3 missDirect = mk3(0.f);
+        float texMetallic = 0.f, texRoughness = 0.f;
+        if (h.prim == -1 && hasEnvMap(s)) missDirect = envLookup(s, ray.d);  // :117-122
         if (h.prim != -1) {
             nHits++;
             fetchSurface(s, h.prim, h.bary, isec);
-            Material material = loadMaterial(s.mats, isec.matId);
+            Material material = texturedMaterial(s, isec);
             material.baseColor = mk3(1.f);  // :125
+            texMetallic = material.metallic;
+            texRoughness = material.roughness;
             if (material.type == Light) {
                 status = -2;
             } else {
@@ -207,9 +217,12 @@ __global__ __launch_bounds__(256) void k_restir_pass1(DScene s, DCamera cam, Pix
             a.state[3 * (long long)idx + 0] = make_float4(isec.norm.x, isec.norm.y, isec.norm.z, isec.wo.x);
             a.state[3 * (long long)idx + 1] =
                 make_float4(isec.wo.y, isec.wo.z, __uint_as_float(rng.scramble), __int_as_float(rng.ptr));
-            a.state[3 * (long long)idx + 2] = make_float4(__int_as_float(status), 0.f, 0.f, 0.f);
+            // a miss carries its env-map colour in the norm/wo slots (unused for a miss)
+            if (status == -1) a.state[3 * (long long)idx + 0] = make_float4(missDirect.x, missDirect.y, missDirect.z, 0.f);
+            a.state[3 * (long long)idx + 2] = make_float4(__int_as_float(status), texMetallic, texRoughness, 0.f);
         } else {
-            restirFinish(s, a, idx, status, isec.norm, isec.wo, reservoir, rng, px.x, px.y, false, directIllum, iter);
+            restirFinish(s, a, idx, status, isec.norm, isec.wo, reservoir, rng, px.x, px.y, false, directIllum, iter,
+                         missDirect, texMetallic, texRoughness);
         }
     }
     if (COUNT) flushCounters(s.counters, nClosest, nAny, nHits, ws);
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(256) void k_restir_pass2(DScene s, PixelMap pm, int
     Sampler rng{s.sobol, __float_as_uint(s1.z), __float_as_int(s1.w)};
     Reservoir reservoir = (status >= 0) ? loadReservoir(a.reservoirTemp, idx) : emptyReservoir();
     restirFinish(s, a, idx, status, mk3(s0.x, s0.y, s0.z), mk3(s0.w, s1.x, s1.y), reservoir, rng, px.x, px.y, true,
-                 directIllum, iter);
+                 directIllum, iter, status == -1 ? mk3(s0.x, s0.y, s0.z) : mk3(0.f), s2.y, s2.z);
 }
 
 }  // namespace rd

@@ -347,13 +347,22 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                 float4 rdw = w.rd[p];
                 v3 rayDir = mk3(rdw.x, rdw.y, rdw.z);
                 do {
-                    if (h.x == -1) {  // miss: primary → direct = 1 (pathtrace.cu:169-172); later → break (:232-247, no env map)
-                        if (k == 0) w.accD[p] = make_float4(1.f, 1.f, 1.f, 0.f);
+                    if (h.x == -1) {  // miss: primary → direct = 1 (pathtrace.cu:169-172); later → env map (:232-247)
+                        if (k == 0) {
+                            w.accD[p] = make_float4(1.f, 1.f, 1.f, 0.f);
+                        } else if (hasEnvMap(s)) {
+                            float4 t = w.thr[p], o = w.ro[p];
+                            v3 radiance = envLookup(s, rayDir) * mk3(t.x, t.y, t.z);
+                            float weight = (rdw.w != 0.f) ? 1.f : powerHeuristic(o.w, environmentMapPdf(s, rayDir));
+                            v3 add = radiance * weight;
+                            float4 a = w.accI[p];
+                            w.accI[p] = make_float4(a.x + add.x, a.y + add.y, a.z + add.z, 0.f);
+                        }
                         break;
                     }
                     Surface isec;
                     fetchSurface(s, h.x, mk2(__int_as_float(h.y), __int_as_float(h.z)), isec);
-                    Material material = loadMaterial(s.mats, isec.matId);
+                    Material material = texturedMaterial(s, isec);
                     v3 throughput;
                     if (k == 0) {
                         material.baseColor = mk3(1.f);  // DENOISER_DEMODULATE (:175-178)
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                     if (!deltaBSDF) {  // NEE (:195-208); the shadow ray itself is traced by trace(k+1)
                         v4 r4 = sample4D(rng);
                         if (s.lightSamplerLength != 0) {
-                            LightPick lp = pickLightPoint(s, r4);
+                            LightPick lp = pickLightPoint(s, isec.pos, r4);
                             v3 radiance = mk3(0.f), wi = mk3(0.f);
                             float lightPdf = lightPdfUnoccluded(s, isec.pos, lp, radiance, wi);
                             float4 n = make_float4(0.f, 0.f, 0.f, -1.f);

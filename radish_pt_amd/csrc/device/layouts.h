@@ -43,10 +43,11 @@ struct __attribute__((aligned(16))) LightRec {
 };
 static_assert(sizeof(LightRec) == 48, "LightRec");
 
-// Material without texture ids (round-1 scope).  32 B.
+// Material (src/material.h:276-286) in three aligned quads.  48 B.
 struct __attribute__((aligned(16))) MatRec {
     float4 a;  // type (int bits), baseColor.xyz
     float4 b;  // metallic, roughness, ior, 0
+    int4 maps; // baseColorMapId, normalMapId, metallicMapId, roughnessMapId (-1 none, -2 procedural base colour)
 };
 
 struct AliasRec {  // BinomialDistrib<float> (src/sampler.h:66-69), unchanged
@@ -66,6 +67,11 @@ struct DScene {
     const LightRec *lights;
     const AliasRec *lightAlias;
     const uint32_t *sobol;
+    const float *texData;   // every texture's texels (vec3), concatenated (src/scene.cpp:464-480)
+    const int4 *texInfo;    // per texture: width, height, first texel, 0   (DevTextureObj, src/image.h:89-91)
+    const AliasRec *envAlias;  // envMapSampler (src/scene.h:512)
+    int envTex;             // envMap's texture id or -1
+    int envSamplerLength;
     Counters *counters;
     int bvhSize;
     int numPrims;

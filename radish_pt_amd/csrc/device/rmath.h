@@ -119,6 +119,38 @@ RD_DEV void sincos_det(float x, float &s, float &c) {
     c = (q == 1 || q == 2) ? -cc : cc;
 }
 
+// atan2 for Math::toPlane (/root/reference/src/mathUtil.h:143-147, CUDA atan2f in the reference): Cephes atanf — range
+// reduction at tan(pi/8) and tan(3pi/8), degree-9 odd polynomial — and its quadrant logic; binary32 operations in this
+// order only (≈2 ulp).
+RD_DEV float atan_det(float xx) {
+    float x = xx < 0.f ? -xx : xx, y;
+    if (x > 2.414213562373095f) {
+        y = 1.5707963267948966f;
+        x = -(1.0f / x);
+    } else if (x > 0.4142135623730950f) {
+        y = 0.7853981633974483f;
+        x = (x - 1.0f) / (x + 1.0f);
+    } else {
+        y = 0.0f;
+    }
+    float z = x * x;
+    y += (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
+    return xx < 0.f ? -y : y;
+}
+RD_DEV float atan2_det(float y, float x) {
+    const float PIF = 3.14159265358979323846f, PIO2F = 1.5707963267948966f;
+    if (x == 0.f) {
+        if (y < 0.f) return -PIO2F;
+        if (y == 0.f) return 0.f;
+        return PIO2F;
+    }
+    if (y == 0.f) return x < 0.f ? PIF : 0.f;
+    float w = 0.f;
+    if (x < 0.f) w = (y < 0.f) ? -PIF : PIF;
+    return w + atan_det(y / x);
+}
+RD_DEV float fract_(float x) { return x - __builtin_floorf(x); }  // glm::fract
+
 RD_DEV uint32_t utilhash(uint32_t a) {  // /root/reference/src/mathUtil.h:199-207
     a = (a + 0x7ed55d16u) + (a << 12);
     a = (a ^ 0xc761c23cu) ^ (a >> 19);

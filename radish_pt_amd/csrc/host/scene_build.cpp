@@ -257,6 +257,19 @@ extern "C" int32_t rdh_build_light_list(const float *vertices, const int32_t *ma
     return count;
 }
 
+extern "C" int32_t rdh_build_envmap_pdf(const float *texels, int32_t width, int32_t height, float *pdfOut) {
+    if (!texels || !pdfOut || width <= 0 || height <= 0) return RDH_HOST_ERR_ARGS;
+    const float PI = 3.1415926535897932384626422832795028841971f;
+    for (int i = 0; i < height; i++)
+        for (int j = 0; j < width; j++) {
+            int idx = i * width + j;
+            const float *c = texels + 3 * (size_t)idx;
+            float lum = 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2];
+            pdfOut[idx] = lum * sinf((.5f + i) / height * PI);
+        }
+    return 0;
+}
+
 extern "C" void rdh_camera_update(void *camera196) {
     struct Cam {
         int32_t resx, resy;

@@ -318,8 +318,18 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
         if (!d->bvhNodes[k]) return fail(c, RDH_ERR_ARGS, "rdh_scene_upload: bvhNodes[%d] is null", k);
     if (d->lightSamplerLength > 0 && (!d->lightSampler || !d->lightPrimIds || !d->lightUnitRadiance))
         return fail(c, RDH_ERR_ARGS, "rdh_scene_upload: light arrays missing");
-    if (d->lightSamplerLength != d->numLights)
-        return fail(c, RDH_ERR_UNSUPPORTED, "environment-map light entry is not supported yet");
+    const bool hasEnv = d->envMapTexId >= 0;
+    if (d->lightSamplerLength != d->numLights + (hasEnv ? 1 : 0))
+        return fail(c, RDH_ERR_ARGS, "lightSamplerLength %d != numLights %d (+1 with an env map)", d->lightSamplerLength, d->numLights);
+    if (d->numTextures < 0 || (d->numTextures > 0 && !d->textures) || d->envMapTexId >= d->numTextures)
+        return fail(c, RDH_ERR_ARGS, "rdh_scene_upload: texture table inconsistent");
+    if (hasEnv) {
+        const rdh_texture &e = d->textures[d->envMapTexId];
+        if (!d->envMapSampler || d->envMapSamplerLength != e.width * e.height)
+            return fail(c, RDH_ERR_ARGS, "envMapSamplerLength %d != env map %dx%d", d->envMapSamplerLength, e.width, e.height);
+    } else if (d->envMapSamplerLength != 0) {
+        return fail(c, RDH_ERR_ARGS, "envMapSampler given without envMapTexId");
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     rdh_scene_free(c);
 
@@ -328,11 +338,26 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
     const HostMaterial *hm = static_cast<const HostMaterial *>(d->materials);
     std::vector<MatRec> mats(d->numMaterials);
     for (int i = 0; i < d->numMaterials; i++) {
-        if (hm[i].map[0] != -1 || hm[i].map[1] != -1 || hm[i].map[2] > -1 || hm[i].map[3] > -1)
-            return fail(c, RDH_ERR_UNSUPPORTED, "material %d uses textures: not supported yet", i);
+        for (int k = 0; k < 4; k++) {  // baseColor may be procedural (-2); the others are -1 or a texture index
+            int id = hm[i].map[k];
+            if (id >= d->numTextures || id < (k == 0 ? -2 : -1))
+                return fail(c, RDH_ERR_ARGS, "material %d: map id %d out of range (numTextures %d)", i, id, d->numTextures);
+        }
         mats[i].a = make_float4(asFloat(hm[i].type), hm[i].color[0], hm[i].color[1], hm[i].color[2]);
         mats[i].b = make_float4(hm[i].metallic, hm[i].roughness, hm[i].ior, 0.f);
+        // Material field order: baseColorMapId, normalMapId, metallicMapId, roughnessMapId (src/material.h:282-285)
+        mats[i].maps = make_int4(hm[i].map[0], hm[i].map[1], hm[i].map[2], hm[i].map[3]);
     }
+    // textures: one blob + {width, height, first texel} per texture (src/scene.cpp:463-486)
+    std::vector<float> texBlob;
+    std::vector<int4> texInfo(std::max(d->numTextures, 1), make_int4(1, 1, 0, 0));
+    for (int i = 0; i < d->numTextures; i++) {
+        const rdh_texture &t = d->textures[i];
+        if (t.width <= 0 || t.height <= 0 || !t.data) return fail(c, RDH_ERR_ARGS, "texture %d is empty", i);
+        texInfo[i] = make_int4(t.width, t.height, (int)(texBlob.size() / 3), 0);
+        texBlob.insert(texBlob.end(), t.data, t.data + 3 * (size_t)t.width * t.height);
+    }
+    if (texBlob.empty()) texBlob.assign(4, 0.f);
 
     const int N = d->numPrims, S = d->bvhSize;
     std::vector<TriRec> tris(N);
@@ -355,6 +380,15 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
     if ((rc = uploadVec(c, tris, &c->ds.tris))) return rc;
     if ((rc = uploadVec(c, attrs, &c->ds.attrs))) return rc;
     if ((rc = uploadVec(c, mats, &c->ds.mats))) return rc;
+    if ((rc = uploadVec(c, texBlob, &c->ds.texData))) return rc;
+    if ((rc = uploadVec(c, texInfo, &c->ds.texInfo))) return rc;
+    std::vector<AliasRec> envAlias(d->envMapSamplerLength);
+    if (d->envMapSamplerLength) memcpy(envAlias.data(), d->envMapSampler, sizeof(AliasRec) * envAlias.size());
+    for (auto &e : envAlias)
+        if (e.failId < 0 || e.failId >= d->envMapSamplerLength) return fail(c, RDH_ERR_ARGS, "env-map alias table failId out of range");
+    if ((rc = uploadVec(c, envAlias, &c->ds.envAlias))) return rc;
+    c->ds.envTex = d->envMapTexId;
+    c->ds.envSamplerLength = d->envMapSamplerLength;
 
     std::vector<NodeRec> nodes(S + 1);  // +1: a readable pad record at index S (speculative next-node loads)
     nodes[S].lo_prim = make_float4(0.f, 0.f, 0.f, asFloat(-1));

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "radish_hip.h"
 
@@ -61,6 +62,15 @@ inline void devSceneCreate(const SceneT &scene, const uint32_t *sobol10kx200) {
     d.lightSamplerLength = static_cast<int32_t>(scene.lightSampler.binomDistribs.size());
     d.lightSampler = scene.lightSampler.binomDistribs.data();
     d.sampleSequence = sobol10kx200;
+    std::vector<rdh_texture> tex(scene.textures.size());
+    for (size_t i = 0; i < tex.size(); i++)
+        tex[i] = rdh_texture{scene.textures[i]->width(), scene.textures[i]->height(),
+                             reinterpret_cast<const float *>(scene.textures[i]->data())};
+    d.numTextures = static_cast<int32_t>(tex.size());
+    d.textures = tex.data();
+    d.envMapTexId = scene.envMapTexId;
+    d.envMapSamplerLength = static_cast<int32_t>(scene.envMapSampler.binomDistribs.size());
+    d.envMapSampler = scene.envMapSampler.binomDistribs.data();
     RADISH_CHECK(rdh_scene_upload(ctx(), &d), "DevScene::create");
 }
 inline void devSceneDestroy() { RADISH_CHECK(rdh_scene_free(ctx()), "DevScene::destroy"); }

@@ -26,6 +26,8 @@ def lib():
         l.rdh_build_alias_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
         l.rdh_build_light_list.restype = C.c_int32
         l.rdh_build_light_list.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 3
+        l.rdh_build_envmap_pdf.restype = C.c_int32
+        l.rdh_build_envmap_pdf.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         l.rdh_camera_update.restype = None
         l.rdh_camera_update.argtypes = [C.c_void_p]
         _lib = l
@@ -71,6 +73,16 @@ def build_light_list(vertices, material_ids, materials):
     if cnt < 0:
         raise RuntimeError(f"rdh_build_light_list failed: {cnt}")
     return prim[:cnt].copy(), rad[:cnt].copy(), power[:cnt].copy()
+
+
+def build_envmap_sampler(texels, width, height):
+    """Alias table over the env map's pixels + its total power (Scene::createLightSampler, src/scene.cpp:146-157)."""
+    t = np.ascontiguousarray(texels, dtype=np.float32).reshape(-1, 3)
+    pdf = np.empty(width * height, dtype=np.float32)
+    rc = lib().rdh_build_envmap_pdf(t.ctypes.data, width, height, pdf.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"rdh_build_envmap_pdf failed: {rc}")
+    return build_alias_table(pdf)
 
 
 def make_camera(width, height, eye, rotation, fovy, lens_radius=0.0, focal_dist=1.0):

@@ -45,8 +45,12 @@ def sobol_table():
 class SceneData:
     """Host arrays of one scene (all numpy, reference layouts)."""
 
-    def __init__(self, name, vertices, normals, texcoords, material_ids, materials):
+    def __init__(self, name, vertices, normals, texcoords, material_ids, materials, textures=(), env_map_tex_id=-1):
+        """textures: list of float32 [h, w, 3] arrays (the reference's `Image` pixels, row-major); material map ids index
+        into it (-1 none, -2 procedural base colour).  env_map_tex_id: index of the environment map or -1."""
         self.name = name
+        self.textures = [np.ascontiguousarray(t, dtype=np.float32) for t in textures]
+        self.env_map_tex_id = int(env_map_tex_id)
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         self.normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
         self.texcoords = np.ascontiguousarray(texcoords, dtype=np.float32).reshape(-1, 2)
@@ -61,8 +65,15 @@ class SceneData:
             self.vertices, self.material_ids, self.materials
         )
         self.num_lights = len(self.light_prim_ids)
-        if self.num_lights:
-            self.light_sampler, s = hostlib.build_alias_table(self.light_power)
+        power = self.light_power
+        if self.env_map_tex_id >= 0:  # Scene::createLightSampler: the env map is the LAST light entry (src/scene.cpp:146-164)
+            env = self.textures[self.env_map_tex_id]
+            self.env_map_sampler, env_sum = hostlib.build_envmap_sampler(env, env.shape[1], env.shape[0])
+            power = np.concatenate([power, np.array([env_sum], np.float32)]).astype(np.float32)
+        else:
+            self.env_map_sampler = np.zeros(0, dtype=L.BINOMIAL_DTYPE)
+        if len(power):
+            self.light_sampler, s = hostlib.build_alias_table(power)
             self.sum_light_power_inv = np.float32(1.0) / np.float32(s)  # src/scene.cpp:527
         else:
             self.light_sampler = np.zeros(0, dtype=L.BINOMIAL_DTYPE)
@@ -156,10 +167,10 @@ class _Builder:
             mat,
         )
 
-    def finish(self, name):
+    def finish(self, name, textures=(), env_map_tex_id=-1):
         return SceneData(
             name, np.concatenate(self.p), np.concatenate(self.n), np.concatenate(self.uv), np.concatenate(self.ids),
-            np.array(self.mats, dtype=L.MATERIAL_DTYPE),
+            np.array(self.mats, dtype=L.MATERIAL_DTYPE), textures, env_map_tex_id,
         )
 
 
@@ -251,6 +262,69 @@ def teapots(segments=64, bands=49, grid=4, emissive_grid=None):
 
 def teapots_camera(width, height):
     return hostlib.make_camera(width, height, eye=(0.3, 1.9, 7.4), rotation=(-91.5, -11.0, 0.0), fovy=19.0)
+
+
+def _checker(w, h, a, b, cells=8):
+    y, x = np.mgrid[0:h, 0:w]
+    m = (((x * cells) // w + (y * cells) // h) % 2).astype(np.float32)[..., None]
+    return (np.asarray(a, np.float32) * (1 - m) + np.asarray(b, np.float32) * m).astype(np.float32)
+
+
+def _sky(w, h):
+    """Small synthetic HDR environment: gradient sky + a bright sun lobe + dim ground (stand-in for an .hdr file)."""
+    v = (np.arange(h, dtype=np.float64) + 0.5) / h
+    u = (np.arange(w, dtype=np.float64) + 0.5) / w
+    V, U = np.meshgrid(v, u, indexing="ij")
+    sky = np.stack([0.25 + 0.3 * (1 - V), 0.4 + 0.35 * (1 - V), 0.7 + 0.3 * (1 - V)], -1) * (V < 0.5)[..., None]
+    ground = np.stack([0.12 + 0 * V, 0.1 + 0 * V, 0.08 + 0 * V], -1) * (V >= 0.5)[..., None]
+    sun = 40.0 * np.exp(-(((U - 0.3) / 0.03) ** 2 + ((V - 0.22) / 0.04) ** 2))
+    return (sky + ground + sun[..., None] * np.array([1.0, 0.9, 0.7])).astype(np.float32)
+
+
+def cornell_textured(segments=16, bands=12, env=True):
+    """Cornell stand-in that exercises every branch of getTexturedMaterialAndSurface (`src/scene.h:88-112`) and the
+    environment map (`:374-414`): checker base-colour texture on the floor, procedural base colour on the back wall,
+    metallic + roughness + normal maps on the metal object, env map visible through the open front."""
+    rng = np.random.default_rng(3)
+    tex = [
+        _checker(32, 32, (0.8, 0.8, 0.8), (0.2, 0.25, 0.6)),                                  # 0 base colour
+        _checker(16, 16, (0.9, 0.9, 0.9), (0.3, 0.3, 0.3), cells=4),                          # 1 metallic (.r)
+        (0.25 + 0.5 * rng.random((8, 8, 1))).repeat(3, axis=2).astype(np.float32),            # 2 roughness (.r)
+        (np.array([0.5, 0.5, 1.0]) + 0.25 * (rng.random((16, 16, 3)) - 0.5)).astype(np.float32),  # 3 normal map
+    ]
+    env_id = -1
+    if env:
+        tex.append(_sky(64, 32))
+        env_id = 4
+    b = _Builder()
+
+    def mat(**kw):
+        maps = {k: kw.pop(k) for k in list(kw) if k.endswith("MapId")}
+        m = L.make_material(**kw)
+        for k, v in maps.items():
+            m[k] = v
+        return b.material(m)
+
+    white = mat(type=L.LAMBERTIAN, baseColor=(0.73, 0.73, 0.73))
+    floor = mat(type=L.LAMBERTIAN, baseColor=(1, 1, 1), baseColorMapId=0)
+    back = mat(type=L.LAMBERTIAN, baseColor=(1, 1, 1), baseColorMapId=-2)
+    red = mat(type=L.LAMBERTIAN, baseColor=(0.63, 0.065, 0.05))
+    green = mat(type=L.LAMBERTIAN, baseColor=(0.14, 0.45, 0.091))
+    light = mat(type=L.LIGHT, baseColor=(17.0, 12.0, 4.0))
+    metal = mat(type=L.METALLIC_WORKFLOW, baseColor=(0.95, 0.8, 0.45), metallic=1.0, roughness=0.3, metallicMapId=1,
+                roughnessMapId=2, normalMapId=3)
+    glass = mat(type=L.DIELECTRIC, baseColor=(1.0, 1.0, 1.0), ior=1.5)
+    x0, x1, y0, y1, z0, z1 = -1, 1, 0, 2, -1, 1
+    b.add(*_quad((x0, y0, z1), (x1, y0, z1), (x1, y0, z0), (x0, y0, z0), (0, 1, 0)), floor)
+    b.add(*_quad((x0, y1, z0), (x1, y1, z0), (x1, y1, z1), (x0, y1, z1), (0, -1, 0)), white)
+    b.add(*_quad((x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (0, 0, 1)), back)
+    b.add(*_quad((x0, y0, z1), (x0, y0, z0), (x0, y1, z0), (x0, y1, z1), (1, 0, 0)), red)
+    b.add(*_quad((x1, y0, z0), (x1, y0, z1), (x1, y1, z1), (x1, y1, z0), (-1, 0, 0)), green)
+    b.ceiling_light(0.0, 0.0, 0.25, 1.999, light)
+    for k, (m_, pos) in enumerate([(metal, (0.45, 0.0, -0.1)), (glass, (-0.35, 0.0, 0.3))]):
+        p, n, uv = _revolved(segments, bands, 0.3, 0.55, k)
+        b.add(p, n, uv, m_, pos)
+    return b.finish("cornell_textured", tex, env_id)
 
 
 def tiny(n_tris=24, seed=1):

@@ -293,6 +293,70 @@ def test_tile_partition_matches_frame(gpu_ctx, cornell_small):
     gpu_ctx.set_partition(0, 1, 64)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Textured materials (base colour / procedural / metallic / roughness / normal map) and the environment map
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env", [True, False])
+def test_textures_and_envmap_bit_exact(gpu_ctx, env):
+    from oracle import pyoracle
+    from radish_pt_amd import api, layouts as L, scenes
+
+    torch = _torch()
+    sd = scenes.cornell_textured(segments=12, bands=8, env=env)
+    gpu_ctx.set_partition(0, 1, 64)
+    gpu_ctx.upload_scene(sd)
+    o = _oracle(sd)
+    W, H, depth = 56, 40, 5
+    n = W * H
+    cam = scenes.cornell_camera(W, H)
+    gpu_ctx.set_camera(cam)
+    ref_d, ref_i = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    for it in range(2):
+        o.path_trace(cam, ref_d, ref_i, it, 60 + it, depth)
+    st = o.stats()
+    for name, flags in (("mega", 0), ("wavefront", api.RDH_PT_WAVEFRONT), ("sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL),
+                        ("persistent", api.RDH_PT_PERSISTENT)):
+        d, i = torch.zeros(n, 3, device="cuda"), torch.zeros(n, 3, device="cuda")
+        gpu_ctx.counters_reset()
+        for it in range(2):
+            gpu_ctx.path_trace(d, i, it, 60 + it, depth, flags | api.RDH_PT_COUNT)
+        assert_bit_equal(d.cpu().numpy(), ref_d, f"{name} direct (env={env})")
+        assert_bit_equal(i.cpu().numpy(), ref_i, f"{name} indirect (env={env})")
+        assert gpu_ctx.counters() == st, name
+    ref = np.zeros((n, 3), np.float32)
+    o.path_trace_direct(cam, ref, 0, 7)
+    dd = torch.zeros(n, 3, device="cuda")
+    gpu_ctx.path_trace_direct(dd, 0, 7)
+    assert_bit_equal(dd.cpu().numpy(), ref, "pathTraceDirect")
+    if env:
+        assert ref[0].max() > 0  # the corner pixel sees the environment map
+    # G-buffer + ReSTIR (two frames: temporal + spatial), textured metallic/roughness carried across the pass boundary
+    gb_ref = pyoracle.GBufferHost(W, H)
+    gb = api.GBuffer()
+    gb.create(W, H)
+    dev = api.DevScene()
+    dev.ctx = gpu_ctx
+    res = [np.zeros(n, L.RESERVOIR_DTYPE) for _ in range(3)]
+    ref_img = np.zeros((n, 3), np.float32)
+    img = torch.zeros(n, 3, device="cuda")
+    gpu_ctx.restir_init()
+    for f in range(2):
+        o.gbuffer_render(cam, gb_ref)
+        gb.render(dev, cam)
+        cur = gb.frameIdx
+        assert_bit_equal(gb.albedo.cpu().numpy(), gb_ref.albedo, "gbuffer albedo")
+        assert_bit_equal(gb.normal[cur].cpu().numpy(), gb_ref.normal[cur], "gbuffer normal")
+        assert np.array_equal(gb.primId[cur].cpu().numpy(), gb_ref.primId[cur])
+        o.restir_direct(cam, ref_img, 0, 80 + f, res[0], res[1], res[2], gb_ref, f == 0, 3, 1)
+        res[0], res[1] = res[1], res[0]
+        gpu_ctx.restir_direct(img, 0, 80 + f, gb.c_struct(cam), 3)
+        assert_bit_equal(img.cpu().numpy(), ref_img, f"ReSTIR frame {f} (env={env})")
+        assert gpu_ctx.restir_read(1).tobytes() == res[1].tobytes()
+        gb_ref.update(cam)
+        gb.update(cam)
+    gpu_ctx.restir_free()
+
+
 def test_error_behaviour(gpu_ctx, cornell_small):
     from radish_pt_amd import api, scenes
 
