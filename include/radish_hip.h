@@ -152,6 +152,14 @@ int rdh_restir_free(rdh_ctx *ctx);
  * the first-frame flag; two launches instead of one so that spatial reuse is race-free. */
 int rdh_restir_direct(rdh_ctx *ctx, float *d_directIllum, int iter, int looper, const rdh_gbuffer *gb,
                       const rdh_restir_params *params, uint32_t flags);
+/* Tile partition (world > 1): rdh_gbuffer_render always renders the WHOLE frame on every rank (temporal and spatial
+ * reuse read the G-buffer at arbitrary / neighbouring pixels); rdh_restir_direct shades this rank's tiles into a
+ * PACKED image buffer (as rdh_path_trace does), computing pass 1 on an 8-pixel apron as well so that pass 2 is local.
+ * Temporal reuse needs last frame's reservoirs of the whole frame: after each rdh_restir_direct call
+ * rdh_restir_exchange_pack(d_packed: float[tilesPerRank][tile^2][9]) → all-gather → rdh_restir_exchange_unpack(d_gathered:
+ * float[world][tilesPerRank][tile^2][9]).  Results are bit-identical to the single-GPU frame. */
+int rdh_restir_exchange_pack(rdh_ctx *ctx, float *d_packed);
+int rdh_restir_exchange_unpack(rdh_ctx *ctx, const float *d_gathered);
 /* Test access to the reservoir buffers (36-byte DirectReservoir[w*h]): which = 0 current out, 1 last, 2 temp. */
 int rdh_restir_read(rdh_ctx *ctx, int which, void *hostOut);
 

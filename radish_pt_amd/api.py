@@ -36,7 +36,7 @@ EXPORTS = [
     "rdh_create", "rdh_destroy", "rdh_last_error", "rdh_set_stream", "rdh_synchronize", "rdh_scene_upload",
     "rdh_scene_free", "rdh_set_camera", "rdh_set_partition", "rdh_tiles_per_rank", "rdh_untile", "rdh_path_trace",
     "rdh_path_trace_direct", "rdh_gbuffer_render", "rdh_restir_init", "rdh_restir_free", "rdh_restir_direct",
-    "rdh_restir_read", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
+    "rdh_restir_read", "rdh_restir_exchange_pack", "rdh_restir_exchange_unpack", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
     "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps",
 ]
 
@@ -113,6 +113,8 @@ def lib():
             "rdh_restir_free": ([vp], i32),
             "rdh_restir_direct": ([vp, vp, i32, i32, C.POINTER(GBufferC), C.POINTER(RestirParamsC), u32], i32),
             "rdh_restir_read": ([vp, i32, vp], i32),
+            "rdh_restir_exchange_pack": ([vp, vp], i32),
+            "rdh_restir_exchange_unpack": ([vp, vp], i32),
             "rdh_trace_closest": ([vp, vp, i64, vp, u32], i32),
             "rdh_trace_occluded": ([vp, vp, i64, vp, u32], i32),
             "rdh_counters_reset": ([vp], i32),
@@ -235,6 +237,12 @@ class Context:
                       faithful_ris=1, flags=0):
         p = RestirParamsC(reuse_mask, ris_count, num_spatial, temporal_clamp, faithful_ris)
         self.check(lib().rdh_restir_direct(self.h, direct.data_ptr(), iter, looper, C.byref(gb_c), C.byref(p), flags))
+
+    def restir_exchange_pack(self, packed):
+        self.check(lib().rdh_restir_exchange_pack(self.h, packed.data_ptr()))
+
+    def restir_exchange_unpack(self, gathered):
+        self.check(lib().rdh_restir_exchange_unpack(self.h, gathered.data_ptr()))
 
     def restir_read(self, which):
         out = np.zeros(self.width * self.height, dtype=L.RESERVOIR_DTYPE)

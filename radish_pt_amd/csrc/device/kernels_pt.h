@@ -312,8 +312,10 @@ __global__ __launch_bounds__(256) void k_gbuffer(DScene s, DCamera cam, DCamera 
 }
 
 // ---- tile reassembly after the all-gather (no reference counterpart) ---------------------------------------------
+// `channels` 32-bit words per pixel: 3 for images, 9 for DirectReservoir records.
 __global__ __launch_bounds__(256) void k_untile(const float *__restrict__ gathered, float *__restrict__ frame, int W,
-                                                int H, int tile, int tilesX, int numTiles, int world, int tilesPerRank) {
+                                                int H, int tile, int tilesX, int numTiles, int world, int tilesPerRank,
+                                                int channels) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)W * H;
     if (i >= total) return;
@@ -322,9 +324,39 @@ __global__ __launch_bounds__(256) void k_untile(const float *__restrict__ gather
     int tileId = ty * tilesX + tx;
     int rank = tileId % world, localTile = tileId / world;
     long long src = ((long long)rank * tilesPerRank + localTile) * (long long)(tile * tile) + (y - ty * tile) * tile + (x - tx * tile);
-    frame[3 * i] = gathered[3 * src];
-    frame[3 * i + 1] = gathered[3 * src + 1];
-    frame[3 * i + 2] = gathered[3 * src + 2];
+    for (int c = 0; c < channels; c++) frame[channels * i + c] = gathered[channels * src + c];
+}
+// frame layout → this rank's packed tile buffer (the send side of the reservoir exchange)
+__global__ __launch_bounds__(256) void k_pack_tiles(const float *__restrict__ frame, float *__restrict__ packed, PixelMap pm,
+                                                    int channels) {
+    unsigned lane = threadIdx.x & 63u;
+    unsigned block = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (block >= (unsigned)pm.numBlocks) return;
+    PixelMap q = pm;
+    q.packed = 1;
+    Pix px = mapPixel(q, block, lane);
+    if (!px.valid) return;
+    for (int c = 0; c < channels; c++) packed[(long long)channels * px.out + c] = frame[(long long)channels * px.index + c];
+}
+
+// This rank's tiles grown by one 8-pixel block on every side (>= the 5-pixel radius of ReSTIR's spatial reuse,
+// restir.cu:45): the pixels whose pass-1 reservoirs this rank's pass 2 may gather.  `out` is unused (frame layout).
+RD_DEV Pix mapPixelApron(const PixelMap &pm, unsigned block, unsigned lane) {
+    Pix p;
+    unsigned bpe = ((unsigned)pm.tile >> 3) + 2u;
+    unsigned bpt = bpe * bpe;
+    unsigned localTile = block / bpt;
+    unsigned b = block - localTile * bpt;
+    unsigned bx = b % bpe, by = b / bpe;
+    unsigned tileId = localTile * (unsigned)pm.world + (unsigned)pm.rank;
+    int tx = int(tileId % (unsigned)pm.tilesX), ty = int(tileId / (unsigned)pm.tilesX);
+    p.x = tx * pm.tile - 8 + int(bx * 8u + (lane & 7u));
+    p.y = ty * pm.tile - 8 + int(by * 8u + (lane >> 3));
+    p.valid = (localTile < (unsigned)pm.tilesPerRank) && (tileId < (unsigned)pm.numTiles) && p.x >= 0 && p.y >= 0 &&
+              p.x < pm.W && p.y < pm.H;
+    p.index = p.y * pm.W + p.x;
+    p.out = p.index;
+    return p;
 }
 
 }  // namespace rd

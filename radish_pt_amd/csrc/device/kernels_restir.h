@@ -120,7 +120,7 @@ RD_DEV Reservoir findSpatialNeighborDisk(const RestirArgs &a, int x, int y, v2 r
 // the textured values pass 1 shaded with (the reference keeps the whole Material in registers across its barrier).
 RD_DEV void restirFinish(const DScene &s, const RestirArgs &a, int idx, int status, v3 norm, v3 wo, Reservoir reservoir,
                          Sampler &rng, int x, int y, bool doSpatial, float *directIllum, int iter, v3 missDirect,
-                         float metallic, float roughness) {
+                         float metallic, float roughness, int outIdx) {
     v3 direct = (status == -2) ? mk3(1.f) : missDirect;
     if (status >= 0) {
         Material material = loadMaterial(s.mats, status);
@@ -145,17 +145,22 @@ RD_DEV void restirFinish(const DScene &s, const RestirArgs &a, int idx, int stat
         if (hasNanOrInf(direct)) direct = mk3(0.f);
     }
     direct = direct * load3(a.albedo, idx);
-    storeRunningMean(directIllum, idx, direct, iter);
+    storeRunningMean(directIllum, outIdx, direct, iter);  // outIdx: frame index, or the packed-tile index when world > 1
 }
 
+// apronBlocks > 0: the launch covers this rank's tiles plus an 8-pixel apron (mapPixelApron) — used with spatial reuse on
+// a tile partition, where pass 2 needs the pass-1 reservoirs of pixels up to 5 px outside the rank's tiles; the apron
+// pixels are computed redundantly by the rank that owns them, with identical results.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_restir_pass1(DScene s, DCamera cam, PixelMap pm, int looper, int iter,
-                                                      RestirArgs a, float *__restrict__ directIllum) {
+                                                      RestirArgs a, float *__restrict__ directIllum, int apronBlocks) {
     unsigned wg;
-    bool wgValid = xcdSwizzle(blockIdx.x, (unsigned)(pm.numBlocks + 3) >> 2, wg);
+    const unsigned nBlocks = apronBlocks > 0 ? (unsigned)apronBlocks : (unsigned)pm.numBlocks;
+    bool wgValid = xcdSwizzle(blockIdx.x, (nBlocks + 3u) >> 2, wg);
     unsigned lane = threadIdx.x & 63u;
-    Pix px = mapPixel(pm, wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u, lane);
-    px.valid = px.valid && wgValid;
+    unsigned blk = wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u;
+    Pix px = apronBlocks > 0 ? mapPixelApron(pm, blk, lane) : mapPixel(pm, blk, lane);
+    px.valid = px.valid && wgValid && blk < nBlocks;
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
     const bool doSpatial = (a.reuseMask & 2) != 0;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void k_restir_pass1(DScene s, DCamera cam, Pix
             a.state[3 * (long long)idx + 2] = make_float4(__int_as_float(status), texMetallic, texRoughness, 0.f);
         } else {
             restirFinish(s, a, idx, status, isec.norm, isec.wo, reservoir, rng, px.x, px.y, false, directIllum, iter,
-                         missDirect, texMetallic, texRoughness);
+                         missDirect, texMetallic, texRoughness, px.out);
         }
     }
     if (COUNT) flushCounters(s.counters, nClosest, nAny, nHits, ws);
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void k_restir_pass2(DScene s, PixelMap pm, int
     Sampler rng{s.sobol, __float_as_uint(s1.z), __float_as_int(s1.w)};
     Reservoir reservoir = (status >= 0) ? loadReservoir(a.reservoirTemp, idx) : emptyReservoir();
     restirFinish(s, a, idx, status, mk3(s0.x, s0.y, s0.z), mk3(s0.w, s1.x, s1.y), reservoir, rng, px.x, px.y, true,
-                 directIllum, iter, status == -1 ? mk3(s0.x, s0.y, s0.z) : mk3(0.f), s2.y, s2.z);
+                 directIllum, iter, status == -1 ? mk3(s0.x, s0.y, s0.z) : mk3(0.f), s2.y, s2.z, px.out);
 }
 
 }  // namespace rd

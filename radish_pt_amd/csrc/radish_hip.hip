@@ -469,7 +469,7 @@ int rdh_untile(rdh_ctx *c, const float *d_gathered, float *d_frame) {
     PixelMap pm = makePixelMap(c);
     long long total = (long long)pm.W * pm.H;
     hipLaunchKernelGGL(k_untile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_gathered, d_frame, pm.W,
-                       pm.H, pm.tile, pm.tilesX, pm.numTiles, pm.world, pm.tilesPerRank);
+                       pm.H, pm.tile, pm.tilesX, pm.numTiles, pm.world, pm.tilesPerRank, 3);
     HIP_TRY(c, hipGetLastError());
     return RDH_OK;
 }
@@ -572,9 +572,17 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
         if (!gb->normal[k] || !gb->depth[k] || !gb->primId[k]) return fail(c, RDH_ERR_ARGS, "rdh_gbuffer_render: null plane");
     if (gb->width != c->cam.resx || gb->height != c->cam.resy)
         return fail(c, RDH_ERR_ARGS, "G-buffer %dx%d does not match camera %dx%d", gb->width, gb->height, c->cam.resx, c->cam.resy);
-    if (c->world > 1) return fail(c, RDH_ERR_UNSUPPORTED, "G-buffer rendering is per-frame (world must be 1)");
     HIP_TRY(c, hipSetDevice(c->device));
+    // The G-buffer is always the WHOLE frame, on every rank: ReSTIR's temporal lookup follows motion vectors to
+    // arbitrary pixels of the previous frame and its spatial lookup crosses tile borders.
     PixelMap pm = makePixelMap(c);
+    if (c->world > 1) {
+        pm.rank = 0;
+        pm.world = 1;
+        pm.tilesPerRank = pm.numTiles;
+        pm.packed = 0;
+        pm.numBlocks = pm.numTiles * (pm.tile / 8) * (pm.tile / 8);
+    }
     DCamera last = toDeviceCamera(gb->lastCam);
     GBufPtrs p{gb->albedo, gb->normal[gb->frameIdx], gb->motion, gb->depth[gb->frameIdx], gb->primId[gb->frameIdx],
                gb->width, gb->height};
@@ -627,7 +635,6 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
     if (!c->resvCur || c->restirPixels != (long long)c->cam.resx * c->cam.resy)
         return fail(c, RDH_ERR_STATE, "rdh_restir_direct before rdh_restir_init (or resolution changed)");
     if (gb->width != c->cam.resx || gb->height != c->cam.resy) return fail(c, RDH_ERR_ARGS, "G-buffer size mismatch");
-    if (c->world > 1) return fail(c, RDH_ERR_UNSUPPORTED, "ReSTIR tile partition is not built yet (world must be 1)");
     if (p->risCount < 0 || p->numSpatial < 0 || p->temporalClamp < 1) return fail(c, RDH_ERR_ARGS, "bad ReSTIR parameters");
     int dims = 4 + p->risCount * 5 + 1 + ((p->reuseMask & 1) ? 1 : 0) + ((p->reuseMask & 2) ? p->numSpatial * 3 + 1 : 0);
     if (dims > 200) return fail(c, RDH_ERR_ARGS, "ReSTIR parameters need %d Sobol dimensions (max 200)", dims);
@@ -654,17 +661,50 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
     a.numSpatial = p->numSpatial;
     a.temporalClamp = p->temporalClamp;
     a.faithfulRIS = p->faithfulRIS;
+    // On a tile partition with spatial reuse, pass 1 also covers an 8-pixel apron around this rank's tiles.
+    int apronBlocks = 0;
+    unsigned grid1 = gridFor(pm);
+    if (c->world > 1 && (p->reuseMask & 2)) {
+        int bpe = pm.tile / 8 + 2;
+        apronBlocks = pm.tilesPerRank * bpe * bpe;
+        unsigned work = (unsigned)(apronBlocks + 3) / 4;
+        grid1 = ((work + 7u) / 8u) * 8u;
+    }
     timeBegin(c);
     if (flags & RDH_PT_COUNT)
-        hipLaunchKernelGGL(k_restir_pass1<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct);
+        hipLaunchKernelGGL(k_restir_pass1<true>, dim3(grid1), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
     else
-        hipLaunchKernelGGL(k_restir_pass1<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct);
+        hipLaunchKernelGGL(k_restir_pass1<false>, dim3(grid1), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
     if (p->reuseMask & 2)
         hipLaunchKernelGGL(k_restir_pass2, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, pm, iter, a, d_direct);
     rc = timeEnd(c, "ReSTIR Direct");
     std::swap(c->resvCur, c->resvLast);  // restir.cu:221
     c->restirFirstFrame = false;         // :223-225
     return rc;
+}
+
+int rdh_restir_exchange_pack(rdh_ctx *c, float *d_packed) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_packed) return fail(c, RDH_ERR_ARGS, "rdh_restir_exchange_pack: null buffer");
+    if (!c->resvLast) return fail(c, RDH_ERR_STATE, "ReSTIR not initialised");
+    PixelMap pm = makePixelMap(c);
+    hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)(pm.numBlocks + 3) / 4), dim3(256), 0, c->stream, c->resvLast, d_packed, pm, 9);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_restir_exchange_unpack(rdh_ctx *c, const float *d_gathered) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_gathered) return fail(c, RDH_ERR_ARGS, "rdh_restir_exchange_unpack: null buffer");
+    if (!c->resvLast) return fail(c, RDH_ERR_STATE, "ReSTIR not initialised");
+    PixelMap pm = makePixelMap(c);
+    long long total = (long long)pm.W * pm.H;
+    hipLaunchKernelGGL(k_untile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_gathered, c->resvLast, pm.W,
+                       pm.H, pm.tile, pm.tilesX, pm.numTiles, pm.world, pm.tilesPerRank, 9);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
 }
 
 int rdh_restir_read(rdh_ctx *c, int which, void *hostOut) {

@@ -293,6 +293,77 @@ def test_tile_partition_matches_frame(gpu_ctx, cornell_small):
     gpu_ctx.set_partition(0, 1, 64)
 
 
+def test_restir_tile_partition_matches_frame(gpu_ctx):
+    """ReSTIR DI on a tile partition (N virtual ranks, one rdh_ctx each, on one GPU): whole-frame G-buffer on every rank,
+    pass 1 over the rank's tiles + 8-px apron, pass 2 local, reservoir exchange (pack -> simulated all-gather -> unpack)
+    for next frame's temporal reuse.  Image and reservoirs must equal the single-GPU frame bit for bit, with a moving
+    camera (motion vectors cross tile borders)."""
+    from radish_pt_amd import api, hostlib, scenes
+
+    torch = _torch()
+    sd = scenes.teapots(segments=12, bands=8, grid=2, emissive_grid=(4, 8))
+    W, H = 150, 90  # not multiples of the tile size
+    n = W * H
+    cams = [hostlib.make_camera(W, H, eye=(0.3 + 0.08 * f, 1.9, 7.4), rotation=(-91.5, -11.0, 0.0), fovy=19.0)
+            for f in range(3)]
+    dev = api.DevScene()
+    dev.ctx = gpu_ctx
+
+    def run(world, tile, reuse):
+        ctxs = []
+        for rank in range(world):
+            c = gpu_ctx if world == 1 else api.Context(0)
+            c.upload_scene(sd)
+            c.set_partition(rank, world, tile)
+            c.set_camera(cams[0])
+            c.restir_init()
+            ctxs.append(c)
+        gb = api.GBuffer()
+        gb.create(W, H)
+        frames, resv = [], []
+        tpr = ctxs[0].tiles_per_rank()
+        imgs = [torch.zeros(n if world == 1 else tpr * tile * tile, 3, device="cuda") for _ in ctxs]
+        for f, cam in enumerate(cams):
+            dev.ctx = ctxs[0]
+            gb.render(dev, cam)  # whole frame regardless of the partition
+            for c, img in zip(ctxs, imgs):
+                c.set_camera(cam)
+                c.restir_direct(img, 0, 40 + f, gb.c_struct(cam), reuse)
+            if world == 1:
+                frames.append(imgs[0].cpu().numpy().copy())
+            else:
+                packs = []
+                for c in ctxs:
+                    pk = torch.zeros(tpr * tile * tile, 9, device="cuda")
+                    c.restir_exchange_pack(pk)
+                    packs.append(pk)
+                gathered = torch.cat(packs).contiguous()
+                for c in ctxs:
+                    c.restir_exchange_unpack(gathered)
+                frame = torch.zeros(n, 3, device="cuda")
+                ctxs[0].untile(torch.cat(imgs).contiguous(), frame)
+                ctxs[0].synchronize()
+                frames.append(frame.cpu().numpy().copy())
+            resv.append([c.restir_read(1).tobytes() for c in ctxs])
+            gb.update(cam)
+        for c in ctxs:
+            c.restir_free()
+            if c is not gpu_ctx:
+                c.close()
+        return frames, resv
+
+    for reuse in (3, 1, 2):
+        ref_frames, ref_resv = run(1, 64, reuse)
+        assert max(f.max() for f in ref_frames) > 0
+        for world, tile in ((2, 64), (3, 32), (5, 16)):
+            frames, resv = run(world, tile, reuse)
+            for f in range(len(cams)):
+                assert_bit_equal(frames[f], ref_frames[f], f"ReSTIR world={world} tile={tile} reuse={reuse} frame {f}")
+                for r in range(world):
+                    assert resv[f][r] == ref_resv[f][0], f"reservoirs world={world} rank {r} frame {f}"
+    gpu_ctx.set_partition(0, 1, 64)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Textured materials (base colour / procedural / metallic / roughness / normal map) and the environment map
 # ---------------------------------------------------------------------------------------------------------------------
