@@ -94,6 +94,9 @@ constexpr int SobolSampleNum = 10000, SobolSampleDim = 200;  // sampler.h:12-13
 struct orc_scene {
     orc_scene_desc d;
     orc_stats st;
+    // analysis hooks (orc_debug_visit_hist): per (ordering, node) visit counts and per-ray visit-count log2 histogram
+    uint32_t *visitHist = nullptr;
+    uint64_t *rayLenHist = nullptr;  // [2][32]: closest / any, bucket = floor(log2(visits))+1, 0 for 0 visits; then [2][32] sums
 };
 
 namespace {
@@ -599,13 +602,16 @@ struct SceneView {
         int closestPrimId = NullPrimitive;
         vec2 closestBary;
         float closestDist = FLT_MAX;
-        const MTBVHNode *nodes = (const MTBVHNode *)d().bvhNodes[getMTBVHId(-ray.direction)];
+        const int ordering = getMTBVHId(-ray.direction);
+        const MTBVHNode *nodes = (const MTBVHNode *)d().bvhNodes[ordering];
         int node = 0;
         const int BVHSize = d().bvhSize;
+        const uint64_t visitsBefore = h->st.nodeVisits;
         while (node != BVHSize) {
             const AABB &bound = boxes()[nodes[node].boundingBoxId];
             float boundDist;
             h->st.nodeVisits++;
+            if (h->visitHist) h->visitHist[(size_t)ordering * BVHSize + node]++;
             bool boundHit = aabbIntersect(bound, ray, boundDist);
             if (boundHit && boundDist < closestDist) {
                 int primId = nodes[node].primitiveId;
@@ -624,6 +630,7 @@ struct SceneView {
                 node = nodes[node].nextNodeIfMiss;
             }
         }
+        logRayLen(0, h->st.nodeVisits - visitsBefore);
         if (closestPrimId != NullPrimitive) {
             h->st.closestHits++;
             getIntersecGeomInfo(closestPrimId, closestBary, intersec);
@@ -666,25 +673,39 @@ struct SceneView {
         dir /= dist;
         dist -= eps;
         Ray ray = makeOffsetedRay(x, dir);
-        const MTBVHNode *nodes = (const MTBVHNode *)d().bvhNodes[getMTBVHId(-ray.direction)];
+        const int ordering = getMTBVHId(-ray.direction);
+        const MTBVHNode *nodes = (const MTBVHNode *)d().bvhNodes[ordering];
         int node = 0;
         const int BVHSize = d().bvhSize;
+        const uint64_t visitsBefore = h->st.nodeVisits;
         while (node != BVHSize) {
             const AABB &bound = boxes()[nodes[node].boundingBoxId];
             float boundDist;
             h->st.nodeVisits++;
+            if (h->visitHist) h->visitHist[(size_t)ordering * BVHSize + node]++;
             bool boundHit = aabbIntersect(bound, ray, boundDist);
             if (boundHit && boundDist < dist) {
                 int primId = nodes[node].primitiveId;
                 if (primId != NullPrimitive) {
-                    if (intersectPrim(primId, ray, dist)) return true;
+                    if (intersectPrim(primId, ray, dist)) {
+                        logRayLen(1, h->st.nodeVisits - visitsBefore);
+                        return true;
+                    }
                 }
                 node++;
             } else {
                 node = nodes[node].nextNodeIfMiss;
             }
         }
+        logRayLen(1, h->st.nodeVisits - visitsBefore);
         return false;
+    }
+    void logRayLen(int kind, uint64_t visits) const {
+        if (!h->rayLenHist) return;
+        int b = 0;
+        for (uint64_t v = visits; v; v >>= 1) b++;
+        h->rayLenHist[kind * 32 + b]++;
+        h->rayLenHist[64 + kind * 32 + b] += visits;
     }
     int lightSample(float r1, float r2) const {  // sampler.h:204-208 (DevDiscreteSampler1D::sample)
         const BinomialDistrib *t = (const BinomialDistrib *)d().lightSampler;
@@ -1006,6 +1027,10 @@ orc_scene *orc_scene_create(const orc_scene_desc *desc) {
 }
 void orc_scene_destroy(orc_scene *s) { delete s; }
 void orc_stats_reset(orc_scene *s) { memset(&s->st, 0, sizeof(s->st)); }
+void orc_debug_visit_hist(orc_scene *s, uint32_t *visitHist, uint64_t *rayLenHist) {
+    s->visitHist = visitHist;
+    s->rayLenHist = rayLenHist;
+}
 void orc_stats_get(const orc_scene *s, orc_stats *out) { *out = s->st; }
 
 void orc_trace_closest(orc_scene *s, const float *rays, int64_t n, orc_hit *hits) {

@@ -37,7 +37,7 @@ EXPORTS = [
     "rdh_scene_free", "rdh_set_camera", "rdh_set_partition", "rdh_tiles_per_rank", "rdh_untile", "rdh_path_trace",
     "rdh_path_trace_direct", "rdh_gbuffer_render", "rdh_restir_init", "rdh_restir_free", "rdh_restir_direct",
     "rdh_restir_read", "rdh_restir_exchange_pack", "rdh_restir_exchange_unpack", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
-    "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps",
+    "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps", "rdh_debug_persist_phases",
 ]
 
 
@@ -123,6 +123,7 @@ def lib():
             "rdh_profile_reset": ([vp], i32),
             "rdh_profile_read": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)], i32),
             "rdh_debug_persist_stamps": ([vp, vp], i32),
+            "rdh_debug_persist_phases": ([vp, vp], i32),
         }
         for name, (args, res) in sig.items():
             fn = getattr(l, name)
@@ -278,6 +279,11 @@ class Context:
     def debug_persist_stamps(self):
         out = np.zeros((3, 4096), dtype=np.uint64)
         self.check(lib().rdh_debug_persist_stamps(self.h, out.ctypes.data))
+        return out
+
+    def debug_persist_phases(self):
+        out = np.zeros(16, dtype=np.uint64)
+        self.check(lib().rdh_debug_persist_phases(self.h, out.ctypes.data))
         return out
 
     def last_kernel_ms(self):

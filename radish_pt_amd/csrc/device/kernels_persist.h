@@ -35,6 +35,12 @@ struct PersistCounters {
 #ifdef RD_PERSIST_STAMPS  // diagnostic build only: when each wave started, ran out of pixels, and ended (wall clock)
     unsigned long long stamp[3][4096];
 #endif
+#ifdef RD_PERSIST_PHASES  // diagnostic build only: where the waves' time goes (s_memtime ticks summed over waves) and how full
+    // the wave is in each phase: [0..5] ticks in raygen / literal+coop / box loop / leaf / retire / shade, [6] total;
+    // [8] box wave-steps, [9] box lane-steps, [10] leaf calls, [11] leaf lanes, [12] shade calls, [13] shade lanes,
+    // [14] raygen calls, [15] raygen lanes
+    unsigned long long phase[16];
+#endif
 };
 
 constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
@@ -84,6 +90,13 @@ __global__ __launch_bounds__(256) void k_persist_schedule(unsigned *__restrict__
 #ifndef RD_PERSIST_WAVES
 #define RD_PERSIST_WAVES 1
 #endif
+#ifdef RD_PERSIST_PHASES
+#define PH_MARK(i) do { unsigned long long _n = __builtin_amdgcn_s_memtime(); phT[i] += _n - phLast; phLast = _n; } while (0)
+#define PH_COUNT(i, mask) do { phT[i] += 1ull; phT[(i) + 1] += (unsigned long long)__popcll(mask); } while (0)
+#else
+#define PH_MARK(i) do { } while (0)
+#define PH_COUNT(i, mask) do { } while (0)
+#endif
 template <bool COUNT>
 __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
                                                        float *__restrict__ directIllum, float *__restrict__ indirectIllum,
@@ -104,6 +117,11 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
 
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
+#ifdef RD_PERSIST_PHASES
+    unsigned long long phT[16] = {0};
+    unsigned long long phLast = __builtin_amdgcn_s_memtime();
+    const unsigned long long phStart = phLast;
+#endif
 #ifdef RD_PERSIST_STAMPS
     const int gw = int(blockIdx.x);
     bool stampedDry = false;
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         unsigned long long idleM = __ballot(state == PS_IDLE);
         int nIdle = __popcll(idleM);
         if (!exhausted && nIdle >= RD_PIX_REFILL_MIN) {
+            PH_COUNT(14, idleM);
             int myRank = __popcll(idleM & laneMaskLt());
             int taken = 0;
             while (taken < nIdle && !exhausted) {
@@ -237,6 +256,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         }
 #endif
 
+        PH_MARK(0);
         // ---------------- literal-class rays: traced whole by the whole wave (traverse.h, coopTraceWhole) ----------------
         {
             unsigned long long lit = __ballot(state == PS_TRACE && rs.cls != 0 && node == 0 && pending < 0 && end != 0);
@@ -262,6 +282,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                 }
             }
         }
+        PH_MARK(1);
         // ---------------- box steps ----------------
         // Run until a quarter of the lanes that entered the loop have stopped walking (parked on a leaf or finished
         // their ray): one ballot + popcount per step is the whole scheduling cost.
@@ -282,13 +303,14 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
             } else if (nStart > 0) {
                 const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
                 do {
+                    PH_COUNT(8, __ballot(walking));
                     if (walking) {
                         float4 lo = nodes[node].lo_prim;
                         float4 hi = nodes[node].hi_next;
                         float boundDist;
                         if (COUNT) ws.nodes++;
                         pathSteps++;
-                        bool boundHit = boxTest(lo, hi, rs, boundDist);
+                        bool boundHit = aabbFast(lo, hi, rs, boundDist);  // every walker here is of class 0 (the others were traced whole above)
                         if (boundHit && boundDist < tmax) {
                             pending = __float_as_int(lo.w);
                             node++;
@@ -303,7 +325,9 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                 //  drain)
             }
         }
+        PH_MARK(2);
         // ---------------- leaf tests of parked lanes ----------------
+        if (__ballot(state == PS_TRACE && pending >= 0) != 0ull) PH_COUNT(10, __ballot(state == PS_TRACE && pending >= 0));
         if (state == PS_TRACE && pending >= 0) {
             TriVerts tv = loadTri(s.tris, pending);
             float dist;
@@ -322,6 +346,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
             }
             pending = -1;
         }
+        PH_MARK(3);
         // ---------------- retire finished traces ----------------
         if (state == PS_TRACE && pending < 0 && node == end) {
             if (isShadow) {
@@ -338,6 +363,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                 state = PS_SHADE;
             }
         }
+        PH_MARK(4);
         // ---------------- shading ----------------
         unsigned long long shadeM = __ballot(state == PS_SHADE);
         if (shadeM != 0ull) {
@@ -345,6 +371,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
             // handful of lanes left, a lane must not wait for every other lane's ray to end before it may continue).
             int nBusy = __popcll(__ballot(state != PS_IDLE));
             if (__popcll(shadeM) * 64 >= nBusy * RD_SHADE_MIN) {
+                PH_COUNT(12, shadeM);
                 if (state == PS_SHADE) {
                     v3 rayDir = rs.d;
                     bool terminate = true;  // set false once a shadow or extension ray is started
@@ -444,7 +471,13 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                 }
             }
         }
+        PH_MARK(5);
     }
+#ifdef RD_PERSIST_PHASES
+    phT[6] = __builtin_amdgcn_s_memtime() - phStart;
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&pc->phase[i], phT[i]);
+#endif
 #ifdef RD_PERSIST_STAMPS
     if (lane == 0 && gw < 4096) pc->stamp[2][gw] = wall_clock64();
 #endif

@@ -797,6 +797,17 @@ int rdh_debug_persist_stamps(rdh_ctx *c, uint64_t *out3x4096) {
 #endif
 }
 
+int rdh_debug_persist_phases(rdh_ctx *c, uint64_t *out16) {
+    if (!c || !out16) return RDH_ERR_ARGS;
+#ifdef RD_PERSIST_PHASES
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out16, c->dPersist->phase, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+    return RDH_OK;
+#else
+    return fail(c, RDH_ERR_UNSUPPORTED, "library built without RD_PERSIST_PHASES");
+#endif
+}
+
 int rdh_last_kernel_ms(rdh_ctx *c, float *ms) {
     if (!c || !ms) return RDH_ERR_ARGS;
     if (!c->timed) return fail(c, RDH_ERR_STATE, "no timed launch yet");
