@@ -160,6 +160,16 @@ int rdh_restir_direct(rdh_ctx *ctx, float *d_directIllum, int iter, int looper, 
  * float[world][tilesPerRank][tile^2][9]).  Results are bit-identical to the single-GPU frame. */
 int rdh_restir_exchange_pack(rdh_ctx *ctx, float *d_packed);
 int rdh_restir_exchange_unpack(rdh_ctx *ctx, const float *d_gathered);
+/* Display path (the step after the hot path): replaces copyImageToPBO's four overloads → sendImageToPBO
+ * (/root/reference/src/pathtrace.cu:32-147; declared src/pathtrace.h:25-29).  d_pbo: uchar4[width*height] (alpha 0).
+ * kind 0: d_image is vec3[w*h], colour = image * scale, tone mapping 0 None / 1 Filmic / 2 ACES (src/common.h:23-25),
+ *         then gamma 1/2.2 (src/mathUtil.h:110-126);
+ * kind 1: vec2[w*h] shown as (r, g, 0); kind 2: float[w*h] shown as grey; kind 3: int[w*h] pixel indices shown as
+ *         normalised (x, y) (the motion-vector view).  toneMapping and scale are read for kind 0 only.
+ * Asynchronous on the context's stream, like the reference's launch. */
+int rdh_copy_image_to_pbo(rdh_ctx *ctx, void *d_pbo, const void *d_image, int width, int height, int kind, int toneMapping,
+                          float scale);
+
 /* Test access to the reservoir buffers (36-byte DirectReservoir[w*h]): which = 0 current out, 1 last, 2 temp. */
 int rdh_restir_read(rdh_ctx *ctx, int which, void *hostOut);
 

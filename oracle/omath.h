@@ -8,6 +8,7 @@
 // kernels execute as well (they carry their own, separately written, copy of these semantics in
 // radish_pt_amd/csrc/device/rmath.h — nothing under oracle/ is included by the product).
 #pragma once
+#include <cstring>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -193,6 +194,48 @@ inline float atan2_det(float y, float x) {
     float w = 0.f;
     if (x < 0.f) w = (y < 0.f) ? -PIF : PIF;
     return w + atan_det(y / x);
+}
+
+
+// ---- gamma --------------------------------------------------------------------------------------
+// Math::gammaCorrection is glm::pow(color, 1/2.2) (mathUtil.h:124-126) = CUDA libdevice powf in the reference.
+// Oracle and HIP both evaluate this fixed recipe instead: log2 of the mantissa folded into [sqrt(1/2), sqrt(2)) by the
+// atanh series, times 1/2.2f, exp2 by a degree-6 polynomial on [-1/2, 1/2]; binary32 operations in the written order.
+inline float pow_gamma_det(float x) {
+    if (!(x > 0.f)) return x == 0.f ? 0.f : NAN;
+    if (x == INFINITY) return x;
+    int eAdj = 0;
+    if (x < 1.17549435e-38f) {
+        x = x * 16777216.f;
+        eAdj = -24;
+    }
+    uint32_t bits;
+    memcpy(&bits, &x, 4);
+    int e = int((bits >> 23) & 0xffu) - 126 + eAdj;
+    uint32_t mb = (bits & 0x007fffffu) | 0x3f000000u;
+    float m;
+    memcpy(&m, &mb, 4);
+    if (m < 0.70710678118654752f) {
+        m = m + m;
+        e = e - 1;
+    }
+    float sN = (m - 1.f) / (m + 1.f);
+    float z = sN * sN;
+    float p = sN + sN * z * (0.333333333333f + z * (0.2f + z * (0.142857142857f + z * 0.111111111111f)));
+    float l2 = p * 2.8853900817779268f;
+    float t = (float(e) + l2) * (1.f / 2.2f);
+    float n = rintf(t);
+    float f = t - n;
+    float q = 1.f + f * (0.69314718056f + f * (0.240226506959f + f * (0.0555041086648f + f * (0.00961812910763f +
+                  f * (0.00133335581464f + f * 0.000154035303934f)))));
+    int ni = (int)n;
+    if (ni < -125) return 0.f;
+    uint32_t qb;
+    memcpy(&qb, &q, 4);
+    qb += (uint32_t)ni << 23;
+    float r;
+    memcpy(&r, &qb, 4);
+    return r;
 }
 
 }  // namespace om

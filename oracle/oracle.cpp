@@ -1235,6 +1235,50 @@ void orc_material_eval(const void *material44, int which, const float *n3, const
         memcpy(&out8[7], &smp.type, 4);
     }
 }
+// sendImageToPBO's four overloads (pathtrace.cu:32-118) on host memory.  kind 0 vec3 (+ tone mapping, scale), 1 vec2,
+// 2 float, 3 int pixel index.  Float → int as on the reference's GPU: NaN → 0, saturating.
+static uint32_t displayByte(float c) {
+    float v = c * 255.f;
+    if (!(v > 0.f)) return 0u;
+    if (v >= 255.f) return 255u;
+    return (uint32_t)(int)v;
+}
+static float displayFilmic1(float c) {  // mathUtil.h:110-113
+    return (c * (c * 0.22f + 0.03f) + 0.002f) / (c * (c * 0.22f + 0.3f) + 0.06f) - 1.f / 30.f;
+}
+void orc_copy_image_to_pbo(uint8_t *pbo, const void *image, int width, int height, int kind, int toneMapping, float scale) {
+    const long long n = (long long)width * height;
+    for (long long idx = 0; idx < n; idx++) {
+        float c[3];
+        if (kind == 0) {
+            const float *img = (const float *)image;
+            for (int k = 0; k < 3; k++) c[k] = img[3 * idx + k] * scale;
+            if (toneMapping == 1) {  // Math::filmic (mathUtil.h:114-116)
+                float d = displayFilmic1(11.2f);
+                for (int k = 0; k < 3; k++) c[k] = displayFilmic1(c[k] * 1.6f) / d;
+            } else if (toneMapping == 2) {  // Math::ACES (mathUtil.h:118-121)
+                for (int k = 0; k < 3; k++) c[k] = (c[k] * (2.51f * c[k] + 0.03f)) / (c[k] * (2.43f * c[k] + 0.59f) + 0.14f);
+            }
+        } else if (kind == 1) {
+            const float *img = (const float *)image;
+            c[0] = img[2 * idx];
+            c[1] = img[2 * idx + 1];
+            c[2] = 0.f;
+        } else if (kind == 2) {
+            c[0] = c[1] = c[2] = ((const float *)image)[idx];
+        } else {
+            int v = ((const int32_t *)image)[idx];
+            int px = v % width, py = v / width;
+            c[0] = float(px) / float(width);
+            c[1] = float(py) / float(height);
+            c[2] = 0.f;
+        }
+        for (int k = 0; k < 3; k++) pbo[4 * idx + k] = (uint8_t)displayByte(om::pow_gamma_det(c[k]));
+        pbo[4 * idx + 3] = 0;
+    }
+}
+float orc_pow_gamma(float x) { return om::pow_gamma_det(x); }
+
 void orc_camera_sample(const void *camera196, int x, int y, const float *r4, float *ray6) {
     Camera cam;
     memcpy(&cam, camera196, sizeof(cam));

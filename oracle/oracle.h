@@ -104,6 +104,11 @@ void orc_restir_direct(orc_scene *s, const void *camera196, float *directIllum, 
                        const orc_gbuffer *gb, int firstFrame, int reuseMask, int faithfulRIS,
                        int numSpatial, int risCount);
 
+/* Display path: sendImageToPBO's four overloads (pathtrace.cu:32-118) on host memory; pbo = uchar4[width*height].
+ * kind 0 vec3 image (tone mapping 0 None / 1 Filmic / 2 ACES, scale), 1 vec2, 2 float, 3 int pixel index. */
+void orc_copy_image_to_pbo(uint8_t *pbo, const void *image, int width, int height, int kind, int toneMapping, float scale);
+float orc_pow_gamma(float x); /* the fixed x^(1/2.2f) recipe both sides use for Math::gammaCorrection */
+
 /* Known-answer-test hooks for single device functions. */
 uint32_t orc_utilhash(uint32_t a);
 int orc_aabb_intersect(const float *box6, const float *ray6, float *tMin);

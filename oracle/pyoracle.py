@@ -79,6 +79,10 @@ def lib():
         l.orc_texture_sample.argtypes = [vp, i32, vp, vp]
         l.orc_material_eval.argtypes = [vp, i32, vp, vp, vp, vp]
         l.orc_camera_sample.argtypes = [vp, i32, i32, vp, vp]
+        l.orc_copy_image_to_pbo.argtypes = [vp, vp, i32, i32, i32, i32, f32]
+        l.orc_copy_image_to_pbo.restype = None
+        l.orc_pow_gamma.argtypes = [f32]
+        l.orc_pow_gamma.restype = f32
         for fn in ("orc_scene_destroy", "orc_stats_reset", "orc_stats_get", "orc_trace_closest", "orc_trace_closest_naive",
                    "orc_trace_occluded", "orc_path_trace", "orc_path_trace_direct", "orc_gbuffer_render",
                    "orc_restir_direct", "orc_sincos", "orc_material_eval", "orc_camera_sample"):
@@ -208,3 +212,15 @@ class OracleScene:
         lib().orc_restir_direct(self.h, cb.ctypes.data, direct.ctypes.data, iter, looper, res_out.ctypes.data,
                                 res_in.ctypes.data, res_temp.ctypes.data, C.byref(g), int(first_frame), reuse_mask,
                                 faithful_ris, num_spatial, ris_count)
+
+
+def copy_image_to_pbo(image, width, height, kind=0, tone_mapping=0, scale=1.0):
+    """sendImageToPBO (pathtrace.cu:32-118) on a host array → uint8 [width*height, 4]."""
+    img = np.ascontiguousarray(image)
+    pbo = np.zeros((width * height, 4), np.uint8)
+    lib().orc_copy_image_to_pbo(pbo.ctypes.data, img.ctypes.data, width, height, kind, tone_mapping, scale)
+    return pbo
+
+
+def pow_gamma(x):
+    return float(lib().orc_pow_gamma(float(x)))

@@ -36,7 +36,7 @@ EXPORTS = [
     "rdh_create", "rdh_destroy", "rdh_last_error", "rdh_set_stream", "rdh_synchronize", "rdh_scene_upload",
     "rdh_scene_free", "rdh_set_camera", "rdh_set_partition", "rdh_tiles_per_rank", "rdh_untile", "rdh_path_trace",
     "rdh_path_trace_direct", "rdh_gbuffer_render", "rdh_restir_init", "rdh_restir_free", "rdh_restir_direct",
-    "rdh_restir_read", "rdh_restir_exchange_pack", "rdh_restir_exchange_unpack", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
+    "rdh_restir_read", "rdh_copy_image_to_pbo", "rdh_restir_exchange_pack", "rdh_restir_exchange_unpack", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
     "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps", "rdh_debug_persist_phases",
 ]
 
@@ -113,6 +113,7 @@ def lib():
             "rdh_restir_free": ([vp], i32),
             "rdh_restir_direct": ([vp, vp, i32, i32, C.POINTER(GBufferC), C.POINTER(RestirParamsC), u32], i32),
             "rdh_restir_read": ([vp, i32, vp], i32),
+            "rdh_copy_image_to_pbo": ([vp, vp, vp, i32, i32, i32, i32, C.c_float], i32),
             "rdh_restir_exchange_pack": ([vp, vp], i32),
             "rdh_restir_exchange_unpack": ([vp, vp], i32),
             "rdh_trace_closest": ([vp, vp, i64, vp, u32], i32),
@@ -238,6 +239,9 @@ class Context:
                       faithful_ris=1, flags=0):
         p = RestirParamsC(reuse_mask, ris_count, num_spatial, temporal_clamp, faithful_ris)
         self.check(lib().rdh_restir_direct(self.h, direct.data_ptr(), iter, looper, C.byref(gb_c), C.byref(p), flags))
+
+    def copy_image_to_pbo(self, pbo, image, width, height, kind=0, tone_mapping=0, scale=1.0):
+        self.check(lib().rdh_copy_image_to_pbo(self.h, pbo.data_ptr(), image.data_ptr(), width, height, kind, tone_mapping, scale))
 
     def restir_exchange_pack(self, packed):
         self.check(lib().rdh_restir_exchange_pack(self.h, packed.data_ptr()))
@@ -381,6 +385,27 @@ def pathTraceDirect(directIllum, iter):
     ctx.path_trace_direct(directIllum, iter, State.looper, Settings.ptFlags & RDH_PT_COUNT)
     ctx.synchronize()
     _advance_looper()
+
+
+class ToneMapping:  # src/common.h:23-25
+    NONE, Filmic, ACES = 0, 1, 2
+
+
+def copyImageToPBO(devPBO, devImage, width, height, toneMapping=ToneMapping.NONE, scale=1.0):
+    """copyImageToPBO's four overloads (src/pathtrace.h:25-29, src/pathtrace.cu:120-147), selected the way C++ overload
+    resolution does — by the image's element type: float32 [n,3] → vec3 (tone-mapped), float32 [n,2] → vec2, float32 [n] →
+    float, int32 [n] → pixel indices.  devPBO: uint8 [n,4]."""
+    torch = _torch()
+    n = width * height
+    if devImage.dtype == torch.int32:
+        kind = 3
+    elif devImage.dtype == torch.float32:
+        kind = {3 * n: 0, 2 * n: 1, n: 2}.get(devImage.numel())
+    else:
+        kind = None
+    if kind is None or devPBO.numel() * devPBO.element_size() != 4 * n:
+        raise RadishError("copyImageToPBO: image/PBO shape does not match width*height")
+    _ctx().copy_image_to_pbo(devPBO, devImage, width, height, kind, toneMapping, scale)
 
 
 def ReSTIRInit():  # src/restir.cu:235-245

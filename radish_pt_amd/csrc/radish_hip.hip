@@ -19,6 +19,7 @@
 #include "device/kernels_restir.h"
 #include "device/kernels_wave.h"
 #include "device/kernels_persist.h"
+#include "device/kernels_display.h"
 
 using namespace rd;
 
@@ -795,6 +796,19 @@ int rdh_debug_persist_stamps(rdh_ctx *c, uint64_t *out3x4096) {
 #else
     return fail(c, RDH_ERR_UNSUPPORTED, "library built without RD_PERSIST_STAMPS");
 #endif
+}
+
+int rdh_copy_image_to_pbo(rdh_ctx *c, void *d_pbo, const void *d_image, int width, int height, int kind, int toneMapping,
+                          float scale) {
+    if (!c) return RDH_ERR_ARGS;
+    if (!d_pbo || !d_image || width <= 0 || height <= 0 || kind < 0 || kind > 3 || toneMapping < 0 || toneMapping > 2)
+        return fail(c, RDH_ERR_ARGS, "rdh_copy_image_to_pbo: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    long long total = (long long)width * height;
+    hipLaunchKernelGGL(k_send_image_to_pbo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       static_cast<uint32_t *>(d_pbo), d_image, width, height, kind, toneMapping, scale);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
 }
 
 int rdh_debug_persist_phases(rdh_ctx *c, uint64_t *out16) {

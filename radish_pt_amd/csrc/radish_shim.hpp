@@ -127,6 +127,20 @@ inline void ReSTIRDirect(glm::vec3 *directIllum, int iter, const GBuffer &gBuffe
     State::looper = (State::looper + 1) % 10000;
 }
 
+// copyImageToPBO (src/pathtrace.h:25-29, src/pathtrace.cu:120-147): asynchronous, like the reference's bare launches.
+inline void copyImageToPBO(uchar4 *devPBO, glm::vec3 *devImage, int width, int height, int toneMapping, float scale = 1.f) {
+    RADISH_CHECK(rdh_copy_image_to_pbo(radish_shim::ctx(), devPBO, devImage, width, height, 0, toneMapping, scale), "copyImageToPBO");
+}
+inline void copyImageToPBO(uchar4 *devPBO, glm::vec2 *devImage, int width, int height) {
+    RADISH_CHECK(rdh_copy_image_to_pbo(radish_shim::ctx(), devPBO, devImage, width, height, 1, 0, 1.f), "copyImageToPBO");
+}
+inline void copyImageToPBO(uchar4 *devPBO, float *devImage, int width, int height) {
+    RADISH_CHECK(rdh_copy_image_to_pbo(radish_shim::ctx(), devPBO, devImage, width, height, 2, 0, 1.f), "copyImageToPBO");
+}
+inline void copyImageToPBO(uchar4 *devPBO, int *devImage, int width, int height) {
+    RADISH_CHECK(rdh_copy_image_to_pbo(radish_shim::ctx(), devPBO, devImage, width, height, 3, 0, 1.f), "copyImageToPBO");
+}
+
 // GBuffer::render (src/gBuffer.cu:83-103); create/destroy/update stay the reference's (plain allocation / a swap).
 inline void GBuffer::render(DevScene *, const Camera &cam) {
     rdh_ctx *c = radish_shim::ctx();

@@ -428,6 +428,41 @@ def test_textures_and_envmap_bit_exact(gpu_ctx, env):
     gpu_ctx.restir_free()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Display path: copyImageToPBO's four overloads (src/pathtrace.cu:32-147) — RGBA8 bytes equal the oracle's
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size", [(37, 29), (1920, 1080)])
+def test_copy_image_to_pbo_bit_exact(gpu_ctx, size):
+    from oracle import pyoracle
+
+    torch = _torch()
+    W, H = size
+    n = W * H
+    rng = np.random.default_rng(7)
+    img = (rng.random((n, 3)).astype(np.float32) ** 3) * 6.0
+    special = np.array([0.0, -0.0, -1.5, np.nan, np.inf, -np.inf, 1e-42, 1.0, 255.0, 1e30], np.float32)
+    img[: len(special), 0] = special
+    img[: len(special), 1] = special[::-1]
+    d_img = _dev(img)
+    pbo = torch.full((n, 4), 77, dtype=torch.uint8, device="cuda")
+    for tone in (0, 1, 2):
+        for scale in (1.0, 0.37):
+            gpu_ctx.copy_image_to_pbo(pbo, d_img, W, H, 0, tone, scale)
+            ref = pyoracle.copy_image_to_pbo(img, W, H, 0, tone, scale)
+            assert np.array_equal(pbo.cpu().numpy(), ref), f"vec3 tone={tone} scale={scale}"
+    rg = rng.random((n, 2)).astype(np.float32) * 1.5 - 0.2
+    gpu_ctx.copy_image_to_pbo(pbo, _dev(rg), W, H, 1)
+    assert np.array_equal(pbo.cpu().numpy(), pyoracle.copy_image_to_pbo(rg, W, H, 1))
+    g = rng.random(n).astype(np.float32) * 3.0
+    gpu_ctx.copy_image_to_pbo(pbo, _dev(g), W, H, 2)
+    assert np.array_equal(pbo.cpu().numpy(), pyoracle.copy_image_to_pbo(g, W, H, 2))
+    mv = rng.integers(-1, n, n).astype(np.int32)
+    gpu_ctx.copy_image_to_pbo(pbo, _dev(mv), W, H, 3)
+    assert np.array_equal(pbo.cpu().numpy(), pyoracle.copy_image_to_pbo(mv, W, H, 3))
+    with pytest.raises(Exception):
+        gpu_ctx.copy_image_to_pbo(pbo, d_img, W, H, 4)
+
+
 def test_error_behaviour(gpu_ctx, cornell_small):
     from radish_pt_amd import api, scenes
 
