@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "radish_pt_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HOST_SOURCES = [os.path.join(CSRC, "host", "scene_build.cpp")]
+HOST_SOURCES = [os.path.join(CSRC, "host", "scene_build.cpp"), os.path.join(CSRC, "host", "scene_load.cpp")]
 HIP_SOURCES = [os.path.join(CSRC, "radish_hip.hip")]
 HIP_DEPS = [
     os.path.join(CSRC, "device", f)
@@ -42,7 +42,7 @@ def build_host(force=False):
     deps = HOST_SOURCES + [os.path.join(ROOT, "include", "radish_host.h")]
     if force or _newer(out, deps):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-o", out]
-             + HOST_SOURCES)
+             + HOST_SOURCES + ["-lz"])
     return out
 
 

@@ -345,3 +345,15 @@ def tiny(n_tris=24, seed=1):
         b.add(p, np.tile(nrm, (3, 1)), np.zeros((3, 2), np.float32), mats[i % 3])
     b.ceiling_light(0.0, 0.0, 0.5, 1.8, light)
     return b.finish("tiny")
+
+
+def load_scene_file(path):
+    """A Radish scene text file (+ the OBJ meshes and textures it names) → (SceneData, camera, settings dict).
+    `Scene::Scene` + `Scene::buildDevData` (/root/reference/src/scene.cpp:108-141,190-249): parsing, mesh/texture loading
+    and flattening happen in libradish_host.so (rdh_scene_parse); SceneData then builds the BVH, the light list and the
+    alias tables exactly as for the procedural scenes."""
+    p = hostlib.parse_scene(path)
+    sd = SceneData(os.path.basename(path), p["vertices"], p["normals"], p["texcoords"], p["material_ids"], p["materials"],
+                   textures=p["textures"], env_map_tex_id=p["env_map_tex_id"])
+    settings = {"trace_depth": p["trace_depth"], "iterations": p["iterations"], "image_name": p["image_name"]}
+    return sd, p["camera"], settings
