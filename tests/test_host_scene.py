@@ -26,7 +26,7 @@ def test_host_library_exports():
 
     header = open(os.path.join(ROOT, "include", "radish_host.h")).read()
     names = sorted(set(re.findall(r"^(?:int|void|int32_t)\s*(rdh_[a-z_]+)\s*\(", header, re.M)))
-    assert len(names) == 5
+    assert len(names) == 7
     for name in names:
         assert hasattr(hostlib.lib(), name)
 
