@@ -484,4 +484,199 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
     if (COUNT) flushCounters(s.counters, nClosest, nAny, nHits, ws);
 }
 
+// ---- renderGBuffer as a persistent launch (gBuffer.cu:3-76) -------------------------------------------------------------
+// k_gbuffer (kernels_pt.h) binds a pixel to a lane for the whole launch, so every wave waits for the longest of its 64
+// primary rays (measured on the teapots scene: 2.97 ms for 2.07 M rays, a quarter of k_pt_persistent's rate).  Here lanes
+// are refilled: a lane whose ray has ended writes its G-buffer record (batched: once 16 lanes wait) and takes the next
+// pixel.  Same centre ray, same walk, same record per pixel as k_gbuffer.
+#ifndef RD_GB_FINISH_MIN
+#define RD_GB_FINISH_MIN 16
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam, DCamera lastCam, PixelMap pm, GBufPtrs gb,
+                                                           PersistCounters *pc) {
+    const int lane = int(threadIdx.x) & 63;
+    const int end = s.bvhSize;
+    const int numBlocks = pm.numBlocks;
+    const int paddedBlocks = int((((unsigned)(numBlocks + 3) / 4u + 7u) / 8u) * 8u * 4u);
+    WalkStats ws{0, 0};
+    unsigned nClosest = 0, nHits = 0;
+    int curBlock = int(blockIdx.x);
+    int slotNext = 0;
+    const int gridWavesN = int(gridDim.x);
+    bool exhausted = curBlock >= paddedBlocks;
+
+    constexpr int G_IDLE = 0, G_TRACE = 1, G_DONE = 2;
+    int state = G_IDLE;
+    int pixIdx = 0;
+    RaySlab rs;
+    rs.o = rs.d = rs.inv = mk3(0.f);
+    rs.cls = 0;
+    const NodeRec *nodes = s.nodes[0];
+    int node = end, pending = -1;
+    float tmax = 0.f;
+    int hitPrim = -1;
+    v2 hitBary = mk2(0.f, 0.f);
+
+    for (;;) {
+        // ---------------- new pixels for idle lanes ----------------
+        const unsigned long long idleM = __ballot(state == G_IDLE);
+        const int nIdle = __popcll(idleM);
+        if (!exhausted && nIdle >= RD_PIX_REFILL_MIN) {
+            const int myRank = __popcll(idleM & laneMaskLt());
+            int taken = 0;
+            while (taken < nIdle && !exhausted) {
+                if (slotNext == 64) {
+                    int b = 0;
+                    if (lane == 0) b = atomicAdd(&pc->blockHead, 1);
+                    curBlock = __shfl(b, 0, 64) + gridWavesN;
+                    slotNext = 0;
+                    if (curBlock >= paddedBlocks) {
+                        exhausted = true;
+                        break;
+                    }
+                }
+                const int avail = 64 - slotNext;
+                const int give = (nIdle - taken) < avail ? (nIdle - taken) : avail;
+                if (state == G_IDLE && myRank >= taken && myRank < taken + give) {
+                    unsigned wgLogical;
+                    const bool ok = xcdSwizzle((unsigned)curBlock >> 2, (unsigned)(numBlocks + 3) >> 2, wgLogical);
+                    const unsigned blk = ok ? wgLogical * 4u + ((unsigned)curBlock & 3u) : 0xffffffffu / 64u;
+                    Pix px = mapPixel(pm, blk, (unsigned)(slotNext + (myRank - taken)));
+                    if (px.valid && ok) {
+                        pixIdx = px.index;
+                        // the un-jittered centre ray of gBuffer.cu:11-26
+                        float aspect = float(cam.resx) / float(cam.resy);
+                        v2 pixelsize = {1.f / float(cam.resx), 1.f / float(cam.resy)};
+                        v2 scr = mk2(float(px.x), float(px.y)) * pixelsize;
+                        v2 ruv = scr + pixelsize * mk2(0.5f, 0.5f);
+                        ruv = {1.f - ruv.x * 2.f, 1.f - ruv.y * 2.f};
+                        v3 pLens = mk3(0.f);
+                        v2 f = (ruv * mk2(aspect, 1.f)) * cam.tanFovY;
+                        v3 pFocus = mk3(f.x, f.y, 1.f) * cam.focalDist;
+                        v3 dir = pFocus - pLens;
+                        Ray ray;
+                        ray.o = cam.position + cam.right * pLens.x + cam.up * pLens.y;
+                        ray.d = normalize(mul(m3{cam.right, cam.up, cam.view}, dir));
+                        rs = makeRaySlab(ray);
+                        nodes = s.nodes[getMTBVHId(-ray.d)];
+                        node = 0;
+                        pending = -1;
+                        hitPrim = -1;
+                        tmax = 3.402823466e+38f;
+                        nClosest++;
+                        state = G_TRACE;
+                    }
+                }
+                slotNext += give;
+                taken += give;
+            }
+        }
+        if (__ballot(state != G_IDLE) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---------------- literal-class rays: traced whole by the whole wave ----------------
+        {
+            unsigned long long lit = __ballot(state == G_TRACE && rs.cls != 0 && node == 0 && pending < 0 && end != 0);
+            while (lit) {
+                const int L = __ffsll((long long)lit) - 1;
+                lit &= lit - 1ull;
+                CoopTrace ct = coopTraceWhole<false>(s, readlanePtr(nodes, L), readlaneRay(rs, L), readlaneF(tmax, L));
+                if (lane == L) {
+                    hitPrim = ct.hitPrim;
+                    hitBary = ct.bary;
+                    tmax = ct.tmax;
+                    node = end;
+                    if (COUNT) {
+                        ws.nodes += ct.nodes;
+                        ws.tris += ct.tris;
+                    }
+                }
+            }
+        }
+        // ---------------- box steps ----------------
+        {
+            bool walking = state == G_TRACE && pending < 0 && node != end;
+            const int nStart = __popcll(__ballot(walking));
+            if (nStart == 1) {
+                const int L = __ffsll((long long)__ballot(walking)) - 1;
+                CoopResult cr = coopWalk(readlanePtr(nodes, L), readlaneI(node, L), end, readlaneRay(rs, L), readlaneF(tmax, L),
+                                         RD_COOP_WINDOWS);
+                if (lane == L) {
+                    node = cr.node;
+                    pending = cr.pending;
+                    if (COUNT) ws.nodes += cr.visited;
+                }
+            } else if (nStart > 0) {
+                const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
+                do {
+                    if (walking) {
+                        float4 lo = nodes[node].lo_prim;
+                        float4 hi = nodes[node].hi_next;
+                        float boundDist;
+                        if (COUNT) ws.nodes++;
+                        bool boundHit = aabbFast(lo, hi, rs, boundDist);
+                        if (boundHit && boundDist < tmax) {
+                            pending = __float_as_int(lo.w);
+                            node++;
+                        } else {
+                            node = __float_as_int(hi.w);
+                        }
+                        walking = pending < 0 && node != end;
+                    }
+                } while (__popcll(__ballot(walking)) >= (minWalk > 1 ? minWalk : 1));
+            }
+        }
+        // ---------------- leaf tests ----------------
+        if (state == G_TRACE && pending >= 0) {
+            TriVerts tv = loadTri(s.tris, pending);
+            float dist;
+            v2 bary;
+            if (COUNT) ws.tris++;
+            bool hit = intersectTriangle(rs, tv.a, tv.b, tv.c, bary, dist);
+            if (hit && dist < tmax) {
+                hitPrim = pending;
+                tmax = dist;
+                hitBary = bary;
+            }
+            pending = -1;
+        }
+        if (state == G_TRACE && pending < 0 && node == end) state = G_DONE;
+        // ---------------- write the records of finished pixels ----------------
+        {
+            const unsigned long long doneM = __ballot(state == G_DONE);
+            const int nBusy = __popcll(__ballot(state != G_IDLE));
+            if (doneM != 0ull && __popcll(doneM) * 64 >= nBusy * RD_GB_FINISH_MIN) {
+                if (state == G_DONE) {
+                    const int idx = pixIdx;
+                    if (hitPrim != -1) {
+                        nHits++;
+                        Surface isec;
+                        fetchSurface(s, hitPrim, hitBary, isec);
+                        int matId = isec.matId;
+                        if (loadMaterial(s.mats, isec.matId).type == Light) matId = -2;  // NullPrimitive - 1 (gBuffer.cu:33-37)
+                        Material material = texturedMaterial(s, isec);                  // :44 (may perturb isec.norm)
+                        store3(gb.albedo, idx, material.baseColor);
+                        store3(gb.normal, idx, isec.norm);
+                        gb.primId[idx] = matId;
+                        gb.depth[idx] = length(rs.o - isec.pos);
+                        v2 ndc = cameraRasterUV(lastCam, isec.pos);
+                        int lx = (int)(float(lastCam.resx) * ndc.x), ly = (int)(float(lastCam.resy) * ndc.y);
+                        gb.motion[idx] = (lx >= 0 && lx < gb.width && ly >= 0 && ly < gb.height) ? ly * cam.resx + lx : -1;
+                    } else {
+                        store3(gb.albedo, idx, hasEnvMap(s) ? envLookup(s, rs.d) : mk3(0.f));  // :61-66
+                        store3(gb.normal, idx, mk3(0.f));
+                        gb.primId[idx] = -1;
+                        gb.depth[idx] = 1.f;
+                        gb.motion[idx] = 0;
+                    }
+                    state = G_IDLE;
+                }
+            }
+        }
+    }
+    if (COUNT) flushCounters(s.counters, nClosest, 0u, nHits, ws);
+}
+
 }  // namespace rd

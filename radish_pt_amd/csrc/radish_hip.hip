@@ -38,6 +38,7 @@ struct rdh_ctx {
     Counters *dCounters = nullptr;
     PersistCounters *dPersist = nullptr;
     unsigned persistGrid = 0;
+    unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned *blockCost = nullptr;  // per-8x8-block cost of the previous persistent launch (k_persist_schedule)
     int *blockOrder = nullptr;
     int costBlocks = 0;             // blocks the two arrays are sized / valid for
@@ -587,11 +588,29 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
     DCamera last = toDeviceCamera(gb->lastCam);
     GBufPtrs p{gb->albedo, gb->normal[gb->frameIdx], gb->motion, gb->depth[gb->frameIdx], gb->primId[gb->frameIdx],
                gb->width, gb->height};
+    if (flags & RDH_PT_MEGA_GBUFFER) {  // one lane per pixel for the whole launch (the reference's structure)
+        timeBegin(c);
+        if (flags & RDH_PT_COUNT)
+            hipLaunchKernelGGL(k_gbuffer<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p);
+        else
+            hipLaunchKernelGGL(k_gbuffer<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p);
+        return timeEnd(c, "renderGBuffer");
+    }
+    // persistent launch with lane refill: as many single-wave workgroups as stay resident, never more than there is work
+    if (c->gbufGrid == 0) {
+        int perCU = 0, cus = 0;
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_gbuffer_persistent<false>, 64, 0));
+        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->gbufGrid = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
+    }
+    unsigned groups = (((unsigned)(pm.numBlocks + 3) / 4 + 7u) / 8u) * 8u * 4u;
+    unsigned grid = groups < c->gbufGrid ? groups : c->gbufGrid;
     timeBegin(c);
+    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, sizeof(PersistCounters), c->stream));
     if (flags & RDH_PT_COUNT)
-        hipLaunchKernelGGL(k_gbuffer<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p);
+        hipLaunchKernelGGL(k_gbuffer_persistent<true>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
     else
-        hipLaunchKernelGGL(k_gbuffer<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p);
+        hipLaunchKernelGGL(k_gbuffer_persistent<false>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
     return timeEnd(c, "renderGBuffer");
 }
 
