@@ -23,7 +23,7 @@ extern "C" {
 #define RDH_OK 0
 #define RDH_ERR_ARGS (-1)        /* null / inconsistent arguments                         */
 #define RDH_ERR_NO_SCENE (-2)    /* call needs rdh_scene_upload + rdh_set_camera first    */
-#define RDH_ERR_UNSUPPORTED (-3) /* a combination that is not built (e.g. ReSTIR with world > 1)           */
+#define RDH_ERR_UNSUPPORTED (-3) /* a combination that is not built (e.g. a diagnostic entry in a non-diagnostic build) */
 #define RDH_ERR_NO_DEVICE (-4)   /* no usable HIP device — there is NO CPU fallback       */
 #define RDH_ERR_STATE (-5)       /* e.g. rdh_restir_direct before rdh_restir_init         */
 
@@ -170,6 +170,30 @@ int rdh_restir_exchange_unpack(rdh_ctx *ctx, const float *d_gathered);
  * Asynchronous on the context's stream, like the reference's launch. */
 int rdh_copy_image_to_pbo(rdh_ctx *ctx, void *d_pbo, const void *d_image, int width, int height, int kind, int toneMapping,
                           float scale);
+
+/* Denoisers (/root/reference/src/denoiser.cu, declared src/denoiser.h).  One entry per reference kernel;
+ * the filter classes (LeveledEAWFilter, SpatioTemporalFilter: buffers + the level schedule, denoiser.cu:411-558) are
+ * composed from them by the C++ shim / the Python mirror.  All images are vec3[w*h] device buffers, variances float[w*h];
+ * gb is the G-buffer rdh_gbuffer_render filled (current planes = gb->frameIdx, last = the other).  Asynchronous on the
+ * context's stream.
+ *   rdh_denoise_eaw                   waveletFilter, EAW (:17-84)  — EAWaveletFilter::filter (:388-397)
+ *   rdh_denoise_svgf                  waveletFilter with variance (:92-173) — EAWaveletFilter::filter (:399-409)
+ *   rdh_denoise_modulate              modulate (:175-185) — modulateAlbedo (:363-371)
+ *   rdh_denoise_add                   add (:187-206) — addImage (:373-386); d_out may be d_in1
+ *   rdh_denoise_temporal_accumulate   temporalAccumulate (:208-262)
+ *   rdh_denoise_estimate_variance     estimateVariance (:264-299)
+ *   rdh_denoise_filter_variance       filterVariance (:301-328)                                                      */
+int rdh_denoise_eaw(rdh_ctx *ctx, float *d_colorOut, const float *d_colorIn, const rdh_gbuffer *gb, const void *camera196,
+                    float sigLumin, float sigNormal, float sigDepth, int level);
+int rdh_denoise_svgf(rdh_ctx *ctx, float *d_colorOut, const float *d_colorIn, float *d_varianceOut, const float *d_varianceIn,
+                     const float *d_filteredVar, const rdh_gbuffer *gb, const void *camera196, float sigLumin, float sigNormal,
+                     float sigDepth, int level);
+int rdh_denoise_modulate(rdh_ctx *ctx, float *d_image, const rdh_gbuffer *gb);
+int rdh_denoise_add(rdh_ctx *ctx, float *d_out, const float *d_in1, const float *d_in2, int width, int height);
+int rdh_denoise_temporal_accumulate(rdh_ctx *ctx, float *d_colorAccumOut, const float *d_colorAccumIn, float *d_momentAccumOut,
+                                    const float *d_momentAccumIn, const float *d_colorIn, const rdh_gbuffer *gb, int first);
+int rdh_denoise_estimate_variance(rdh_ctx *ctx, float *d_variance, const float *d_moment, int width, int height);
+int rdh_denoise_filter_variance(rdh_ctx *ctx, float *d_varianceOut, const float *d_varianceIn, int width, int height);
 
 /* Test access to the reservoir buffers (36-byte DirectReservoir[w*h]): which = 0 current out, 1 last, 2 temp. */
 int rdh_restir_read(rdh_ctx *ctx, int which, void *hostOut);

@@ -238,4 +238,59 @@ inline float pow_gamma_det(float x) {
     return r;
 }
 
+
+// ---- exp / pow for the denoisers' weights (denoiser.cu:70-77,139-150; glm::exp / glm::pow = CUDA libdevice in the
+// reference).  Fixed binary32 recipes, evaluated identically by the HIP kernels (device/kernels_denoise.h).
+inline float exp_det(float x) {
+    if (!(x == x)) return x;
+    if (x > 88.7f) return INFINITY;
+    if (x < -87.3f) return 0.f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = (x - n * 0.693359375f) - n * -2.12194440e-4f;
+    float p = 1.f + r * (1.f + r * (0.5f + r * (0.166666671633720f + r * (0.0416666679084301f +
+                  r * (0.00833333376795053f + r * 0.00138888892252f)))));
+    uint32_t pb;
+    memcpy(&pb, &p, 4);
+    pb += (uint32_t)(int)n << 23;
+    float out;
+    memcpy(&out, &pb, 4);
+    return out;
+}
+inline float pow_det(float x, float y) {
+    if (!(x > 0.f)) return (x == 0.f && y > 0.f) ? 0.f : ((x == 0.f && y == 0.f) ? 1.f : NAN);
+    if (x == INFINITY) return x;
+    int eAdj = 0;
+    if (x < 1.17549435e-38f) {
+        x = x * 16777216.f;
+        eAdj = -24;
+    }
+    uint32_t bits;
+    memcpy(&bits, &x, 4);
+    int e = int((bits >> 23) & 0xffu) - 126 + eAdj;
+    uint32_t mb = (bits & 0x007fffffu) | 0x3f000000u;
+    float m;
+    memcpy(&m, &mb, 4);
+    if (m < 0.70710678118654752f) {
+        m = m + m;
+        e = e - 1;
+    }
+    float sN = (m - 1.f) / (m + 1.f);
+    float z = sN * sN;
+    float p = sN + sN * z * (0.333333333333f + z * (0.2f + z * (0.142857142857f + z * 0.111111111111f)));
+    float l2 = p * 2.8853900817779268f;
+    float t = (float(e) + l2) * y;
+    if (t > 127.9f) return INFINITY;
+    if (t < -125.9f) return 0.f;
+    float n = rintf(t);
+    float f = t - n;
+    float q = 1.f + f * (0.69314718056f + f * (0.240226506959f + f * (0.0555041086648f + f * (0.00961812910763f +
+                  f * (0.00133335581464f + f * 0.000154035303934f)))));
+    uint32_t qb;
+    memcpy(&qb, &q, 4);
+    qb += (uint32_t)(int)n << 23;
+    float r;
+    memcpy(&r, &qb, 4);
+    return r;
+}
+
 }  // namespace om

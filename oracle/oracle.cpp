@@ -1278,6 +1278,203 @@ void orc_copy_image_to_pbo(uint8_t *pbo, const void *image, int width, int heigh
     }
 }
 float orc_pow_gamma(float x) { return om::pow_gamma_det(x); }
+float orc_exp(float x) { return om::exp_det(x); }
+float orc_pow(float x, float y) { return om::pow_det(x, y); }
+
+// ---- denoisers (denoiser.cu), on host memory ----------------------------------------------------------------------------
+namespace {
+const float kG3[3][3] = {{.075f, .124f, .075f}, {.124f, .204f, .124f}, {.075f, .124f, .075f}};
+const float kG5[5][5] = {{.0030f, .0133f, .0219f, .0133f, .0030f},
+                         {.0133f, .0596f, .0983f, .0596f, .0133f},
+                         {.0219f, .0983f, .1621f, .0983f, .0219f},
+                         {.0133f, .0596f, .0983f, .0596f, .0133f},
+                         {.0030f, .0133f, .0219f, .0133f, .0030f}};
+inline vec3 ld3(const float *p, int i) { return vec3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+inline void st3(float *p, int i, vec3 v) {
+    p[3 * i] = v.x;
+    p[3 * i + 1] = v.y;
+    p[3 * i + 2] = v.z;
+}
+vec3 camGetPosition(const Camera &cam, int x, int y, float dist) {  // sceneStructs.h:50-70
+    float aspect = float(cam.resx) / cam.resy;
+    float tanFovY = camTanFovY(cam);
+    vec2 pixelSize = vec2(1.f / float(cam.resx), 1.f / float(cam.resy));
+    vec2 scr = vec2(float(x), float(y)) * pixelSize;
+    vec2 ruv = scr + pixelSize * .5f;
+    ruv = vec2(1.f - ruv.x * 2.f, 1.f - ruv.y * 2.f);
+    vec3 pLens = vec3(0.f);
+    vec2 f = ruv * vec2(aspect, 1.f) * tanFovY;
+    vec3 pFocus = vec3(f.x, f.y, 1.f) * cam.focalDist;
+    vec3 dir = pFocus - pLens;
+    dir = normalize(mat3{cam.right, cam.up, cam.view} * dir);
+    vec3 ori = cam.position + cam.right * pLens.x + cam.up * pLens.y;
+    return ori + dir * dist;
+}
+}  // namespace
+
+void orc_denoise_eaw(float *colorOut, const float *colorIn, const orc_gbuffer *gb, const void *camera196, float sigLumin,
+                     float sigNormal, float sigDepth, int level) {  // denoiser.cu:17-84
+    Camera cam;
+    memcpy(&cam, camera196, sizeof(cam));
+    const int f = gb->frameIdx, step = 1 << level;
+    const int *primId = gb->primId[f];
+    const float *normal = gb->normal[f], *depth = gb->depth[f];
+    for (int y = 0; y < cam.resy; y++)
+        for (int x = 0; x < cam.resx; x++) {
+            int idxP = x + y * cam.resx;
+            int primIdP = primId[idxP];
+            if (primIdP <= NullPrimitive) {
+                st3(colorOut, idxP, ld3(colorIn, idxP));
+                continue;
+            }
+            vec3 colorP = ld3(colorIn, idxP), normalP = ld3(normal, idxP);
+            vec3 posP = camGetPosition(cam, x, y, depth[idxP]);
+            vec3 sum(0.f);
+            float weightSum = 0.f;
+            for (int i = -2; i <= 2; i++)
+                for (int j = -2; j <= 2; j++) {
+                    int qx = x + j * step, qy = y + i * step;
+                    if (qx >= cam.resx || qy >= cam.resy || qx < 0 || qy < 0) continue;
+                    int idxQ = qx + qy * cam.resx;
+                    if (primId[idxQ] != primIdP) continue;
+                    vec3 normalQ = ld3(normal, idxQ);
+                    vec3 posQ = camGetPosition(cam, qx, qy, depth[idxQ]);
+                    vec3 colorQ = ld3(colorIn, idxQ);
+                    float wColor = gmin(1.f, exp_det(-dot(colorP - colorQ, colorP - colorQ) / sigLumin));
+                    float wNormal = gmin(1.f, exp_det(-dot(normalP - normalQ, normalP - normalQ) / sigNormal));
+                    float wPos = gmin(1.f, exp_det(-dot(posP - posQ, posP - posQ) / sigDepth));
+                    float weight = wColor * wNormal * wPos * kG5[i + 2][j + 2];
+                    sum = sum + colorQ * weight;
+                    weightSum += weight;
+                }
+            st3(colorOut, idxP, (weightSum == 0.f) ? ld3(colorIn, idxP) : sum / weightSum);
+        }
+}
+
+void orc_denoise_svgf(float *colorOut, const float *colorIn, float *varianceOut, const float *varianceIn, const float *varFiltered,
+                      const orc_gbuffer *gb, const void *camera196, float sigLumin, float sigNormal, float sigDepth,
+                      int level) {  // denoiser.cu:92-173
+    Camera cam;
+    memcpy(&cam, camera196, sizeof(cam));
+    const int f = gb->frameIdx, step = 1 << level;
+    const int *primId = gb->primId[f];
+    const float *normal = gb->normal[f], *depth = gb->depth[f];
+    for (int y = 0; y < cam.resy; y++)
+        for (int x = 0; x < cam.resx; x++) {
+            int idxP = x + y * cam.resx;
+            if (primId[idxP] <= NullPrimitive) {
+                st3(colorOut, idxP, ld3(colorIn, idxP));
+                varianceOut[idxP] = varianceIn[idxP];
+                continue;
+            }
+            vec3 colorP = ld3(colorIn, idxP), normalP = ld3(normal, idxP);
+            vec3 posP = camGetPosition(cam, x, y, depth[idxP]);
+            vec3 colorSum(0.f);
+            float varianceSum = 0.f, weightSum = 0.f, weight2Sum = 0.f;
+            for (int i = -2; i <= 2; i++)
+                for (int j = -2; j <= 2; j++) {
+                    int qx = x + j * step, qy = y + i * step;
+                    if (qx >= cam.resx || qy >= cam.resy || qx < 0 || qy < 0) continue;
+                    int idxQ = qx + qy * cam.resx;
+                    vec3 normalQ = ld3(normal, idxQ);
+                    vec3 posQ = camGetPosition(cam, qx, qy, depth[idxQ]);
+                    float varQ = varianceIn[idxQ];
+                    vec3 colorQ = ld3(colorIn, idxQ);
+                    float wPos = exp_det(-dot(posP - posQ, posP - posQ) / (sigDepth + 1e-4f));
+                    float wNormal = pow_det(satDot(normalP, normalQ), sigNormal) + 1e-4f;
+                    float denom = sigLumin * sqrtf(gmax(varFiltered[idxP], 0.f)) + 1e-4f;
+                    float wColor = exp_det(-fabsf(luminance(colorP) - luminance(colorQ)) / denom) + 1e-4f;
+                    float weight = wColor * wNormal * wPos * kG5[i + 2][j + 2];
+                    float weight2 = weight * weight;
+                    colorSum = colorSum + colorQ * weight;
+                    varianceSum += varQ * weight2;
+                    weightSum += weight;
+                    weight2Sum += weight2;
+                }
+            st3(colorOut, idxP, (weightSum < FLT_EPSILON) ? ld3(colorIn, idxP) : colorSum / weightSum);
+            varianceOut[idxP] = (weight2Sum < FLT_EPSILON) ? varianceIn[idxP] : varianceSum / weight2Sum;
+        }
+}
+
+void orc_denoise_modulate(float *image, const orc_gbuffer *gb) {  // denoiser.cu:175-185; LDRToHDR = identity (mathUtil.h:53-56)
+    for (int i = 0; i < gb->width * gb->height; i++) {
+        vec3 c = ld3(image, i) / 1.f, a = ld3(gb->albedo, i);
+        st3(image, i, c * vec3(gmax(a.x, 0.f), gmax(a.y, 0.f), gmax(a.z, 0.f)));
+    }
+}
+void orc_denoise_add(float *out, const float *in1, const float *in2, int width, int height) {  // denoiser.cu:187-206
+    for (long long i = 0; i < 3ll * width * height; i++) out[i] = in1[i] + in2[i];
+}
+
+void orc_denoise_temporal_accumulate(float *colorAccumOut, const float *colorAccumIn, float *momentAccumOut,
+                                     const float *momentAccumIn, const float *colorIn, const orc_gbuffer *gb, int first) {
+    const float alpha = 0.2f;  // denoiser.cu:208-262
+    const int f = gb->frameIdx;
+    for (int idx = 0; idx < gb->width * gb->height; idx++) {
+        int primId = gb->primId[f][idx], lastIdx = gb->motion[idx];
+        bool diff = first != 0;
+        if (lastIdx < 0) diff = true;
+        else if (primId <= NullPrimitive) diff = true;
+        else if (gb->primId[f ^ 1][lastIdx] != primId) diff = true;
+        else if (fabsf(dot(ld3(gb->normal[f], idx), ld3(gb->normal[f ^ 1], lastIdx))) < .1f) diff = true;
+        vec3 color = ld3(colorIn, idx);
+        float lum = luminance(color);
+        vec3 colorAccum, momentAccum;
+        if (diff) {
+            colorAccum = color;
+            momentAccum = vec3(lum, lum * lum, 0.f);
+        } else {
+            vec3 lastColor = ld3(colorAccumIn, lastIdx), lastMoment = ld3(momentAccumIn, lastIdx);
+            colorAccum = lastColor * (1.f - alpha) + color * alpha;
+            momentAccum = vec3(lastMoment.x * (1.f - alpha) + lum * alpha, lastMoment.y * (1.f - alpha) + (lum * lum) * alpha,
+                               lastMoment.z + 1.f);
+        }
+        st3(colorAccumOut, idx, colorAccum);
+        st3(momentAccumOut, idx, momentAccum);
+    }
+}
+
+void orc_denoise_estimate_variance(float *variance, const float *moment, int width, int height) {  // denoiser.cu:264-299
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            int idx = x + y * width;
+            vec3 m = ld3(moment, idx);
+            if (m.z > 3.5f) {
+                variance[idx] = m.y - m.x * m.x;
+            } else {
+                float sx = 0.f, sy = 0.f;
+                int pixelCount = 0;
+                for (int i = -1; i <= 1; i++)
+                    for (int j = -1; j <= 1; j++) {
+                        int qx = x + j, qy = y + i;
+                        if (qx < 0 || qx >= width || qy < 0 || qy >= height) continue;
+                        vec3 q = ld3(moment, qx + qy * width);
+                        sx += q.x;
+                        sy += q.y;
+                        pixelCount++;
+                    }
+                sx = sx / float(pixelCount);
+                sy = sy / float(pixelCount);
+                variance[idx] = sy - sx * sx;
+            }
+        }
+}
+
+void orc_denoise_filter_variance(float *varianceOut, const float *varianceIn, int width, int height) {  // denoiser.cu:301-328
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            float sum = 0.f, weightSum = 0.f;
+            for (int i = -1; i <= 1; i++)
+                for (int j = -1; j <= 1; j++) {
+                    int qx = x + i, qy = y + j;
+                    if (qx < 0 || qx >= width || qy < 0 || qy >= height) continue;
+                    float weight = kG3[i + 1][j + 1];
+                    sum += varianceIn[qx + qy * width] * weight;
+                    weightSum += weight;
+                }
+            varianceOut[x + y * width] = sum / weightSum;
+        }
+}
 
 void orc_camera_sample(const void *camera196, int x, int y, const float *r4, float *ray6) {
     Camera cam;

@@ -109,6 +109,22 @@ void orc_restir_direct(orc_scene *s, const void *camera196, float *directIllum, 
 void orc_copy_image_to_pbo(uint8_t *pbo, const void *image, int width, int height, int kind, int toneMapping, float scale);
 float orc_pow_gamma(float x); /* the fixed x^(1/2.2f) recipe both sides use for Math::gammaCorrection */
 
+/* Denoisers (denoiser.cu) on host memory: EAW filter (:17-84), SVGF filter with variance (:92-173), modulate (:175-185),
+ * add (:187-206), temporalAccumulate (:208-262), estimateVariance (:264-299), filterVariance (:301-328).  gb supplies the
+ * current (frameIdx) and last planes; width/height are gb's. */
+void orc_denoise_eaw(float *colorOut, const float *colorIn, const orc_gbuffer *gb, const void *camera196, float sigLumin,
+                     float sigNormal, float sigDepth, int level);
+void orc_denoise_svgf(float *colorOut, const float *colorIn, float *varianceOut, const float *varianceIn, const float *varFiltered,
+                      const orc_gbuffer *gb, const void *camera196, float sigLumin, float sigNormal, float sigDepth, int level);
+void orc_denoise_modulate(float *image, const orc_gbuffer *gb);
+void orc_denoise_add(float *out, const float *in1, const float *in2, int width, int height);
+void orc_denoise_temporal_accumulate(float *colorAccumOut, const float *colorAccumIn, float *momentAccumOut,
+                                     const float *momentAccumIn, const float *colorIn, const orc_gbuffer *gb, int first);
+void orc_denoise_estimate_variance(float *variance, const float *moment, int width, int height);
+void orc_denoise_filter_variance(float *varianceOut, const float *varianceIn, int width, int height);
+float orc_exp(float x);          /* the fixed e^x recipe of the denoisers' weights */
+float orc_pow(float x, float y); /* the fixed x^y recipe (x >= 0) */
+
 /* Known-answer-test hooks for single device functions. */
 uint32_t orc_utilhash(uint32_t a);
 int orc_aabb_intersect(const float *box6, const float *ray6, float *tMin);

@@ -83,6 +83,19 @@ def lib():
         l.orc_copy_image_to_pbo.restype = None
         l.orc_pow_gamma.argtypes = [f32]
         l.orc_pow_gamma.restype = f32
+        l.orc_exp.argtypes, l.orc_exp.restype = [f32], f32
+        l.orc_pow.argtypes, l.orc_pow.restype = [f32, f32], f32
+        G = C.POINTER(GBufferC)
+        l.orc_denoise_eaw.argtypes = [vp, vp, G, vp, f32, f32, f32, i32]
+        l.orc_denoise_svgf.argtypes = [vp, vp, vp, vp, vp, G, vp, f32, f32, f32, i32]
+        l.orc_denoise_modulate.argtypes = [vp, G]
+        l.orc_denoise_add.argtypes = [vp, vp, vp, i32, i32]
+        l.orc_denoise_temporal_accumulate.argtypes = [vp, vp, vp, vp, vp, G, i32]
+        l.orc_denoise_estimate_variance.argtypes = [vp, vp, i32, i32]
+        l.orc_denoise_filter_variance.argtypes = [vp, vp, i32, i32]
+        for fn in ("orc_denoise_eaw", "orc_denoise_svgf", "orc_denoise_modulate", "orc_denoise_add",
+                   "orc_denoise_temporal_accumulate", "orc_denoise_estimate_variance", "orc_denoise_filter_variance"):
+            getattr(l, fn).restype = None
         for fn in ("orc_scene_destroy", "orc_stats_reset", "orc_stats_get", "orc_trace_closest", "orc_trace_closest_naive",
                    "orc_trace_occluded", "orc_path_trace", "orc_path_trace_direct", "orc_gbuffer_render",
                    "orc_restir_direct", "orc_sincos", "orc_material_eval", "orc_camera_sample"):
@@ -224,3 +237,56 @@ def copy_image_to_pbo(image, width, height, kind=0, tone_mapping=0, scale=1.0):
 
 def pow_gamma(x):
     return float(lib().orc_pow_gamma(float(x)))
+
+
+# ---- denoisers (denoiser.cu) on host arrays -----------------------------------------------------------------------------
+def _cam_bytes(cam):
+    return np.frombuffer(np.asarray(cam).tobytes(), np.uint8).copy()
+
+
+def denoise_eaw(color_in, gb, cam, sig_lumin, sig_normal, sig_depth, level):
+    out = np.zeros_like(color_in)
+    g, cb = gb.c_struct(), _cam_bytes(cam)
+    lib().orc_denoise_eaw(out.ctypes.data, color_in.ctypes.data, C.byref(g), cb.ctypes.data, sig_lumin, sig_normal, sig_depth, level)
+    return out
+
+
+def denoise_svgf(color_in, var_in, var_filtered, gb, cam, sig_lumin, sig_normal, sig_depth, level):
+    out, var_out = np.zeros_like(color_in), np.zeros_like(var_in)
+    g, cb = gb.c_struct(), _cam_bytes(cam)
+    lib().orc_denoise_svgf(out.ctypes.data, color_in.ctypes.data, var_out.ctypes.data, var_in.ctypes.data, var_filtered.ctypes.data,
+                           C.byref(g), cb.ctypes.data, sig_lumin, sig_normal, sig_depth, level)
+    return out, var_out
+
+
+def denoise_modulate(image, gb):
+    out = image.copy()
+    g = gb.c_struct()
+    lib().orc_denoise_modulate(out.ctypes.data, C.byref(g))
+    return out
+
+
+def denoise_add(in1, in2, width, height):
+    out = np.zeros_like(in1)
+    lib().orc_denoise_add(out.ctypes.data, in1.ctypes.data, in2.ctypes.data, width, height)
+    return out
+
+
+def denoise_temporal_accumulate(color_accum_in, moment_accum_in, color_in, gb, first):
+    c_out, m_out = np.zeros_like(color_in), np.zeros_like(color_in)
+    g = gb.c_struct()
+    lib().orc_denoise_temporal_accumulate(c_out.ctypes.data, color_accum_in.ctypes.data, m_out.ctypes.data,
+                                          moment_accum_in.ctypes.data, color_in.ctypes.data, C.byref(g), 1 if first else 0)
+    return c_out, m_out
+
+
+def denoise_estimate_variance(moment, width, height):
+    var = np.zeros(width * height, np.float32)
+    lib().orc_denoise_estimate_variance(var.ctypes.data, moment.ctypes.data, width, height)
+    return var
+
+
+def denoise_filter_variance(var_in, width, height):
+    out = np.zeros_like(var_in)
+    lib().orc_denoise_filter_variance(out.ctypes.data, var_in.ctypes.data, width, height)
+    return out

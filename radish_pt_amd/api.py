@@ -37,7 +37,8 @@ EXPORTS = [
     "rdh_create", "rdh_destroy", "rdh_last_error", "rdh_set_stream", "rdh_synchronize", "rdh_scene_upload",
     "rdh_scene_free", "rdh_set_camera", "rdh_set_partition", "rdh_tiles_per_rank", "rdh_untile", "rdh_path_trace",
     "rdh_path_trace_direct", "rdh_gbuffer_render", "rdh_restir_init", "rdh_restir_free", "rdh_restir_direct",
-    "rdh_restir_read", "rdh_copy_image_to_pbo", "rdh_restir_exchange_pack", "rdh_restir_exchange_unpack", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
+    "rdh_restir_read", "rdh_copy_image_to_pbo", "rdh_denoise_eaw", "rdh_denoise_svgf", "rdh_denoise_modulate",
+    "rdh_denoise_add", "rdh_denoise_temporal_accumulate", "rdh_denoise_estimate_variance", "rdh_denoise_filter_variance", "rdh_restir_exchange_pack", "rdh_restir_exchange_unpack", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
     "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps", "rdh_debug_persist_phases",
 ]
 
@@ -115,6 +116,13 @@ def lib():
             "rdh_restir_direct": ([vp, vp, i32, i32, C.POINTER(GBufferC), C.POINTER(RestirParamsC), u32], i32),
             "rdh_restir_read": ([vp, i32, vp], i32),
             "rdh_copy_image_to_pbo": ([vp, vp, vp, i32, i32, i32, i32, C.c_float], i32),
+            "rdh_denoise_eaw": ([vp, vp, vp, C.POINTER(GBufferC), vp] + [C.c_float] * 3 + [i32], i32),
+            "rdh_denoise_svgf": ([vp, vp, vp, vp, vp, vp, C.POINTER(GBufferC), vp] + [C.c_float] * 3 + [i32], i32),
+            "rdh_denoise_modulate": ([vp, vp, C.POINTER(GBufferC)], i32),
+            "rdh_denoise_add": ([vp, vp, vp, vp, i32, i32], i32),
+            "rdh_denoise_temporal_accumulate": ([vp, vp, vp, vp, vp, vp, C.POINTER(GBufferC), i32], i32),
+            "rdh_denoise_estimate_variance": ([vp, vp, vp, i32, i32], i32),
+            "rdh_denoise_filter_variance": ([vp, vp, vp, i32, i32], i32),
             "rdh_restir_exchange_pack": ([vp, vp], i32),
             "rdh_restir_exchange_unpack": ([vp, vp], i32),
             "rdh_trace_closest": ([vp, vp, i64, vp, u32], i32),
@@ -243,6 +251,39 @@ class Context:
 
     def copy_image_to_pbo(self, pbo, image, width, height, kind=0, tone_mapping=0, scale=1.0):
         self.check(lib().rdh_copy_image_to_pbo(self.h, pbo.data_ptr(), image.data_ptr(), width, height, kind, tone_mapping, scale))
+
+    # ---- denoisers (src/denoiser.cu) ----
+    @staticmethod
+    def _cam_buf(cam):
+        return np.frombuffer(np.asarray(cam, dtype=L.CAMERA_DTYPE).tobytes(), np.uint8).copy()
+
+    def denoise_eaw(self, color_out, color_in, gb_c, cam, sig_lumin, sig_normal, sig_depth, level):
+        cb = self._cam_buf(cam)
+        self.check(lib().rdh_denoise_eaw(self.h, color_out.data_ptr(), color_in.data_ptr(), C.byref(gb_c), cb.ctypes.data,
+                                         sig_lumin, sig_normal, sig_depth, level))
+
+    def denoise_svgf(self, color_out, color_in, var_out, var_in, var_filtered, gb_c, cam, sig_lumin, sig_normal, sig_depth, level):
+        cb = self._cam_buf(cam)
+        self.check(lib().rdh_denoise_svgf(self.h, color_out.data_ptr(), color_in.data_ptr(), var_out.data_ptr(), var_in.data_ptr(),
+                                          var_filtered.data_ptr(), C.byref(gb_c), cb.ctypes.data, sig_lumin, sig_normal,
+                                          sig_depth, level))
+
+    def denoise_modulate(self, image, gb_c):
+        self.check(lib().rdh_denoise_modulate(self.h, image.data_ptr(), C.byref(gb_c)))
+
+    def denoise_add(self, out, in1, in2, width, height):
+        self.check(lib().rdh_denoise_add(self.h, out.data_ptr(), in1.data_ptr(), in2.data_ptr(), width, height))
+
+    def denoise_temporal_accumulate(self, color_out, color_in_accum, moment_out, moment_in_accum, color_in, gb_c, first):
+        self.check(lib().rdh_denoise_temporal_accumulate(self.h, color_out.data_ptr(), color_in_accum.data_ptr(),
+                                                         moment_out.data_ptr(), moment_in_accum.data_ptr(),
+                                                         color_in.data_ptr(), C.byref(gb_c), 1 if first else 0))
+
+    def denoise_estimate_variance(self, variance, moment, width, height):
+        self.check(lib().rdh_denoise_estimate_variance(self.h, variance.data_ptr(), moment.data_ptr(), width, height))
+
+    def denoise_filter_variance(self, var_out, var_in, width, height):
+        self.check(lib().rdh_denoise_filter_variance(self.h, var_out.data_ptr(), var_in.data_ptr(), width, height))
 
     def restir_exchange_pack(self, packed):
         self.check(lib().rdh_restir_exchange_pack(self.h, packed.data_ptr()))
@@ -479,4 +520,109 @@ class GBuffer:
 
     def update(self, cam):  # src/gBuffer.cu:78-81
         self.lastCam = np.asarray(cam, dtype=L.CAMERA_DTYPE).copy()
+        self.frameIdx ^= 1
+
+
+# ======================================================================================================================
+# Denoisers: the reference's filter classes (src/denoiser.h:16-77, src/denoiser.cu:388-558) over the rdh_denoise_* entries
+# ======================================================================================================================
+def modulateAlbedo(devImage, gBuffer):  # src/denoiser.cu:363-371
+    _ctx().denoise_modulate(devImage, gBuffer.c_struct())
+
+
+def addImage(out, in1, in2=None, width=None, height=None):
+    """addImage(devImage, in, w, h) and addImage(out, in1, in2, w, h) (src/denoiser.cu:373-386)."""
+    if in2 is None or isinstance(in2, int):  # two-image overload: addImage(devImage, in, width, height)
+        width, height = (in2, width) if isinstance(in2, int) else (width, height)
+        in1, in2 = out, in1
+    _ctx().denoise_add(out, in1, in2, width, height)
+
+
+class EAWaveletFilter:  # src/denoiser.h:16-36
+    def __init__(self, width=0, height=0, sigLumin=0.0, sigNormal=0.0, sigDepth=0.0):
+        self.width, self.height = width, height
+        self.sigLumin, self.sigNormal, self.sigDepth = sigLumin, sigNormal, sigDepth
+
+    def filter(self, colorOut, colorIn, gBuffer, cam, level, varianceOut=None, varianceIn=None, filteredVar=None):
+        ctx = _ctx()
+        if varianceOut is None:  # src/denoiser.cu:388-397
+            ctx.denoise_eaw(colorOut, colorIn, gBuffer.c_struct(), cam, self.sigLumin, self.sigNormal, self.sigDepth, level)
+        else:  # src/denoiser.cu:399-409
+            ctx.denoise_svgf(colorOut, colorIn, varianceOut, varianceIn, filteredVar, gBuffer.c_struct(), cam, self.sigLumin,
+                             self.sigNormal, self.sigDepth, level)
+
+
+class LeveledEAWFilter:  # src/denoiser.h:38-49, src/denoiser.cu:411-434
+    def create(self, width, height, level, device=0):
+        torch = _torch()
+        self.level = level
+        self.waveletFilter = EAWaveletFilter(width, height, 64.0, 0.2, 1.0)
+        self.tmpImg = torch.zeros(width * height, 3, device=torch.device("cuda", device))
+
+    def destroy(self):
+        self.tmpImg = None
+
+    def filter(self, colorOut, colorIn, gBuffer, cam):
+        """Five à-trous passes (levels 0..4, as in the reference, whatever `level` says).  `colorOut` is `glm::vec3 *&` in the
+        reference — the result ends up in what was tmpImg; returns the tensor that holds it."""
+        f = self.waveletFilter
+        f.filter(colorOut, colorIn, gBuffer, cam, 0)
+        for lv in (1, 2, 3, 4):
+            f.filter(self.tmpImg, colorOut, gBuffer, cam, lv)
+            colorOut, self.tmpImg = self.tmpImg, colorOut
+        return colorOut
+
+
+class SpatioTemporalFilter:  # src/denoiser.h:51-77, src/denoiser.cu:436-560
+    def create(self, width, height, level, device=0):
+        torch = _torch()
+        dev = torch.device("cuda", device)
+        self.level = level
+        self.accumColor = [torch.zeros(width * height, 3, device=dev) for _ in range(2)]
+        self.accumMoment = [torch.zeros(width * height, 3, device=dev) for _ in range(2)]
+        self.variance = torch.zeros(width * height, device=dev)
+        self.waveletFilter = EAWaveletFilter(width, height, 4.0, 128.0, 1.0)
+        self.tmpColor = torch.zeros(width * height, 3, device=dev)
+        self.tmpVar = torch.zeros(width * height, device=dev)
+        self.filteredVar = torch.zeros(width * height, device=dev)
+        self.firstTime = True
+        self.frameIdx = 0
+
+    def destroy(self):
+        self.accumColor = self.accumMoment = self.variance = self.tmpColor = self.tmpVar = self.filteredVar = None
+
+    def temporalAccumulate(self, colorIn, gBuffer):  # :461-485
+        f = self.frameIdx
+        _ctx().denoise_temporal_accumulate(self.accumColor[f], self.accumColor[f ^ 1], self.accumMoment[f], self.accumMoment[f ^ 1],
+                                           colorIn, gBuffer.c_struct(), self.firstTime)
+        self.firstTime = False
+
+    def estimateVariance(self):  # :487-509
+        w = self.waveletFilter
+        _ctx().denoise_estimate_variance(self.variance, self.accumMoment[self.frameIdx], w.width, w.height)
+
+    def filterVariance(self):  # :511-523
+        w = self.waveletFilter
+        _ctx().denoise_filter_variance(self.filteredVar, self.variance, w.width, w.height)
+
+    def filter(self, colorOut, colorIn, gBuffer, cam):
+        """src/denoiser.cu:525-558, swap for swap.  Returns the tensor that holds the result (`colorOut` is `glm::vec3 *&`)."""
+        f, w = self.frameIdx, self.waveletFilter
+        self.temporalAccumulate(colorIn, gBuffer)
+        self.estimateVariance()
+        self.filterVariance()
+        w.filter(colorOut, self.accumColor[f], gBuffer, cam, 0, self.tmpVar, self.variance, self.filteredVar)
+        colorOut, self.accumColor[f] = self.accumColor[f], colorOut
+        self.tmpVar, self.variance = self.variance, self.tmpVar
+        self.filterVariance()
+        w.filter(colorOut, self.accumColor[f], gBuffer, cam, 1, self.tmpVar, self.variance, self.filteredVar)
+        self.tmpVar, self.variance = self.variance, self.tmpVar
+        for lv in (2, 3, 4):
+            self.filterVariance()
+            w.filter(self.tmpColor, colorOut, gBuffer, cam, lv, self.tmpVar, self.variance, self.filteredVar)
+            self.tmpColor, colorOut = colorOut, self.tmpColor
+            self.tmpVar, self.variance = self.variance, self.tmpVar
+        return colorOut
+
+    def nextFrame(self):  # :560
         self.frameIdx ^= 1

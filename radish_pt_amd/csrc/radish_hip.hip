@@ -20,6 +20,7 @@
 #include "device/kernels_wave.h"
 #include "device/kernels_persist.h"
 #include "device/kernels_display.h"
+#include "device/kernels_denoise.h"
 
 using namespace rd;
 
@@ -826,6 +827,104 @@ int rdh_copy_image_to_pbo(rdh_ctx *c, void *d_pbo, const void *d_image, int widt
     long long total = (long long)width * height;
     hipLaunchKernelGGL(k_send_image_to_pbo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                        static_cast<uint32_t *>(d_pbo), d_image, width, height, kind, toneMapping, scale);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+// ---- denoisers (src/denoiser.cu) -----------------------------------------------------------------------------------------
+namespace {
+int denoiseGB(rdh_ctx *c, const rdh_gbuffer *gb, DenoiseGB &d, const char *what) {
+    if (!gb || !gb->albedo || !gb->motion || gb->frameIdx < 0 || gb->frameIdx > 1 || gb->width <= 0 || gb->height <= 0)
+        return fail(c, RDH_ERR_ARGS, "%s: bad G-buffer", what);
+    for (int k = 0; k < 2; k++)
+        if (!gb->normal[k] || !gb->depth[k] || !gb->primId[k]) return fail(c, RDH_ERR_ARGS, "%s: null G-buffer plane", what);
+    const int f = gb->frameIdx;
+    d = DenoiseGB{gb->albedo, gb->normal[f], gb->normal[f ^ 1], gb->depth[f], gb->motion, gb->primId[f], gb->primId[f ^ 1],
+                  gb->width, gb->height};
+    return RDH_OK;
+}
+dim3 denoiseGrid(int w, int h) { return dim3((unsigned)((w + 31) / 32), (unsigned)((h + 7) / 8)); }
+}  // namespace
+
+int rdh_denoise_eaw(rdh_ctx *c, float *d_colorOut, const float *d_colorIn, const rdh_gbuffer *gb, const void *camera196,
+                    float sigLumin, float sigNormal, float sigDepth, int level) {
+    if (!c || !d_colorOut || !d_colorIn || !camera196 || level < 0 || level > 16) return c ? fail(c, RDH_ERR_ARGS, "rdh_denoise_eaw: bad arguments") : RDH_ERR_ARGS;
+    DenoiseGB d;
+    int rc = denoiseGB(c, gb, d, "rdh_denoise_eaw");
+    if (rc) return rc;
+    DCamera cam = toDeviceCamera(camera196);
+    if (cam.resx != gb->width || cam.resy != gb->height) return fail(c, RDH_ERR_ARGS, "rdh_denoise_eaw: camera / G-buffer size mismatch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_eaw_filter, denoiseGrid(cam.resx, cam.resy), dim3(256), 0, c->stream, d_colorOut, d_colorIn, d, sigDepth,
+                       sigNormal, sigLumin, cam, level);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_denoise_svgf(rdh_ctx *c, float *d_colorOut, const float *d_colorIn, float *d_varianceOut, const float *d_varianceIn,
+                     const float *d_filteredVar, const rdh_gbuffer *gb, const void *camera196, float sigLumin, float sigNormal,
+                     float sigDepth, int level) {
+    if (!c || !d_colorOut || !d_colorIn || !d_varianceOut || !d_varianceIn || !d_filteredVar || !camera196 || level < 0 || level > 16)
+        return c ? fail(c, RDH_ERR_ARGS, "rdh_denoise_svgf: bad arguments") : RDH_ERR_ARGS;
+    DenoiseGB d;
+    int rc = denoiseGB(c, gb, d, "rdh_denoise_svgf");
+    if (rc) return rc;
+    DCamera cam = toDeviceCamera(camera196);
+    if (cam.resx != gb->width || cam.resy != gb->height) return fail(c, RDH_ERR_ARGS, "rdh_denoise_svgf: camera / G-buffer size mismatch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_svgf_filter, denoiseGrid(cam.resx, cam.resy), dim3(256), 0, c->stream, d_colorOut, d_colorIn, d_varianceOut,
+                       d_varianceIn, d_filteredVar, d, sigDepth, sigNormal, sigLumin, cam, level);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_denoise_modulate(rdh_ctx *c, float *d_image, const rdh_gbuffer *gb) {
+    if (!c || !d_image) return c ? fail(c, RDH_ERR_ARGS, "rdh_denoise_modulate: bad arguments") : RDH_ERR_ARGS;
+    DenoiseGB d;
+    int rc = denoiseGB(c, gb, d, "rdh_denoise_modulate");
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    long long n = (long long)gb->width * gb->height;
+    hipLaunchKernelGGL(k_modulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_image, d.albedo, n);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_denoise_add(rdh_ctx *c, float *d_out, const float *d_in1, const float *d_in2, int width, int height) {
+    if (!c || !d_out || !d_in1 || !d_in2 || width <= 0 || height <= 0) return c ? fail(c, RDH_ERR_ARGS, "rdh_denoise_add: bad arguments") : RDH_ERR_ARGS;
+    HIP_TRY(c, hipSetDevice(c->device));
+    long long n3 = 3ll * width * height;
+    hipLaunchKernelGGL(k_add_images, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, c->stream, d_out, d_in1, d_in2, n3);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_denoise_temporal_accumulate(rdh_ctx *c, float *d_colorAccumOut, const float *d_colorAccumIn, float *d_momentAccumOut,
+                                    const float *d_momentAccumIn, const float *d_colorIn, const rdh_gbuffer *gb, int first) {
+    if (!c || !d_colorAccumOut || !d_colorAccumIn || !d_momentAccumOut || !d_momentAccumIn || !d_colorIn)
+        return c ? fail(c, RDH_ERR_ARGS, "rdh_denoise_temporal_accumulate: bad arguments") : RDH_ERR_ARGS;
+    DenoiseGB d;
+    int rc = denoiseGB(c, gb, d, "rdh_denoise_temporal_accumulate");
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_temporal_accumulate, denoiseGrid(gb->width, gb->height), dim3(256), 0, c->stream, d_colorAccumOut,
+                       d_colorAccumIn, d_momentAccumOut, d_momentAccumIn, d_colorIn, d, first);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_denoise_estimate_variance(rdh_ctx *c, float *d_variance, const float *d_moment, int width, int height) {
+    if (!c || !d_variance || !d_moment || width <= 0 || height <= 0) return c ? fail(c, RDH_ERR_ARGS, "rdh_denoise_estimate_variance: bad arguments") : RDH_ERR_ARGS;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_estimate_variance, denoiseGrid(width, height), dim3(256), 0, c->stream, d_variance, d_moment, width, height);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_denoise_filter_variance(rdh_ctx *c, float *d_varianceOut, const float *d_varianceIn, int width, int height) {
+    if (!c || !d_varianceOut || !d_varianceIn || width <= 0 || height <= 0) return c ? fail(c, RDH_ERR_ARGS, "rdh_denoise_filter_variance: bad arguments") : RDH_ERR_ARGS;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_filter_variance, denoiseGrid(width, height), dim3(256), 0, c->stream, d_varianceOut, d_varianceIn, width, height);
     HIP_TRY(c, hipGetLastError());
     return RDH_OK;
 }

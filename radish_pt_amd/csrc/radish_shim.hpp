@@ -151,4 +151,101 @@ inline void GBuffer::render(DevScene *, const Camera &cam) {
     float ms = 0.f;
     if (rdh_last_kernel_ms(c, &ms) == RDH_OK) std::printf("GBuffer runtime%.3f ms\n", ms);  // src/gBuffer.cu:98
 }
+// ---- denoiser.cu (src/denoiser.h:16-81): the filter classes keep the reference's declarations; these are their bodies ----
+#ifdef RADISH_SHIM_WITH_DENOISER  // needs "denoiser.h" (EAWaveletFilter, LeveledEAWFilter, SpatioTemporalFilter) and hip_runtime_api.h
+namespace radish_shim {
+template <typename T>
+inline T *devAlloc(size_t n) {  // cudaMalloc<T> (src/cudaUtil.h)
+    void *p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) check(RDH_ERR_NO_DEVICE, "hipMalloc", __FILE__, __LINE__);
+    hipMemset(p, 0, n * sizeof(T));
+    return static_cast<T *>(p);
+}
+inline float *f(glm::vec3 *p) { return reinterpret_cast<float *>(p); }
+}  // namespace radish_shim
+
+inline void modulateAlbedo(glm::vec3 *devImage, const GBuffer &gBuffer) {  // denoiser.cu:363-371
+    rdh_gbuffer g = radish_shim::toC(gBuffer);
+    RADISH_CHECK(rdh_denoise_modulate(radish_shim::ctx(), radish_shim::f(devImage), &g), "modulate");
+}
+inline void addImage(glm::vec3 *devImage, glm::vec3 *in, int width, int height) {  // :373-378
+    RADISH_CHECK(rdh_denoise_add(radish_shim::ctx(), radish_shim::f(devImage), radish_shim::f(devImage), radish_shim::f(in), width, height), "add");
+}
+inline void addImage(glm::vec3 *out, glm::vec3 *in1, glm::vec3 *in2, int width, int height) {  // :380-386
+    RADISH_CHECK(rdh_denoise_add(radish_shim::ctx(), radish_shim::f(out), radish_shim::f(in1), radish_shim::f(in2), width, height), "add");
+}
+inline void EAWaveletFilter::filter(glm::vec3 *colorOut, glm::vec3 *colorIn, const GBuffer &gBuffer, const Camera &cam, int level) {
+    rdh_gbuffer g = radish_shim::toC(gBuffer);  // :388-397
+    RADISH_CHECK(rdh_denoise_eaw(radish_shim::ctx(), radish_shim::f(colorOut), radish_shim::f(colorIn), &g, &cam, sigLumin, sigNormal,
+                                 sigDepth, level), "EAW Filter");
+}
+inline void EAWaveletFilter::filter(glm::vec3 *colorOut, glm::vec3 *colorIn, float *varianceOut, float *varianceIn, float *filteredVar,
+                                    const GBuffer &gBuffer, const Camera &cam, int level) {
+    rdh_gbuffer g = radish_shim::toC(gBuffer);  // :399-409
+    RADISH_CHECK(rdh_denoise_svgf(radish_shim::ctx(), radish_shim::f(colorOut), radish_shim::f(colorIn), varianceOut, varianceIn,
+                                  filteredVar, &g, &cam, sigLumin, sigNormal, sigDepth, level), "SVGF Filter");
+}
+inline void LeveledEAWFilter::create(int width, int height, int level) {  // :411-415
+    this->level = level;
+    waveletFilter = EAWaveletFilter(width, height, 64.f, .2f, 1.f);
+    tmpImg = radish_shim::devAlloc<glm::vec3>((size_t)width * height);
+}
+inline void LeveledEAWFilter::destroy() { hipFree(tmpImg); tmpImg = nullptr; }
+inline void LeveledEAWFilter::filter(glm::vec3 *&colorOut, glm::vec3 *colorIn, const GBuffer &gBuffer, const Camera &cam) {
+    waveletFilter.filter(colorOut, colorIn, gBuffer, cam, 0);  // :419-434
+    for (int lv = 1; lv <= 4; lv++) {
+        waveletFilter.filter(tmpImg, colorOut, gBuffer, cam, lv);
+        std::swap(colorOut, tmpImg);
+    }
+}
+inline void SpatioTemporalFilter::create(int width, int height, int level) {  // :436-448
+    this->level = level;
+    for (int i = 0; i < 2; i++) {
+        accumColor[i] = radish_shim::devAlloc<glm::vec3>((size_t)width * height);
+        accumMoment[i] = radish_shim::devAlloc<glm::vec3>((size_t)width * height);
+    }
+    variance = radish_shim::devAlloc<float>((size_t)width * height);
+    waveletFilter = EAWaveletFilter(width, height, 4.f, 128.f, 1.f);
+    tmpColor = radish_shim::devAlloc<glm::vec3>((size_t)width * height);
+    tmpVar = radish_shim::devAlloc<float>((size_t)width * height);
+    filteredVar = radish_shim::devAlloc<float>((size_t)width * height);
+}
+inline void SpatioTemporalFilter::destroy() {  // :450-459
+    for (int i = 0; i < 2; i++) { hipFree(accumColor[i]); hipFree(accumMoment[i]); }
+    hipFree(variance); hipFree(tmpColor); hipFree(tmpVar); hipFree(filteredVar);
+}
+inline void SpatioTemporalFilter::temporalAccumulate(glm::vec3 *colorIn, const GBuffer &gBuffer) {  // :461-485
+    rdh_gbuffer g = radish_shim::toC(gBuffer);
+    RADISH_CHECK(rdh_denoise_temporal_accumulate(radish_shim::ctx(), radish_shim::f(accumColor[frameIdx]), radish_shim::f(accumColor[frameIdx ^ 1]),
+                                                 radish_shim::f(accumMoment[frameIdx]), radish_shim::f(accumMoment[frameIdx ^ 1]),
+                                                 radish_shim::f(colorIn), &g, firstTime ? 1 : 0), "SpatioTemporalFilter::temporalAccumulate");
+    firstTime = false;
+}
+inline void SpatioTemporalFilter::estimateVariance() {  // :487-509
+    RADISH_CHECK(rdh_denoise_estimate_variance(radish_shim::ctx(), variance, radish_shim::f(accumMoment[frameIdx]), waveletFilter.width,
+                                               waveletFilter.height), "SpatioTemporalFilter::estimateVariance");
+}
+inline void SpatioTemporalFilter::filterVariance() {  // :511-523
+    RADISH_CHECK(rdh_denoise_filter_variance(radish_shim::ctx(), filteredVar, variance, waveletFilter.width, waveletFilter.height),
+                 "SpatioTemporalFilter::filterVariance");
+}
+inline void SpatioTemporalFilter::filter(glm::vec3 *&colorOut, glm::vec3 *colorIn, const GBuffer &gBuffer, const Camera &cam) {
+    temporalAccumulate(colorIn, gBuffer);  // :525-558, swap for swap
+    estimateVariance();
+    filterVariance();
+    waveletFilter.filter(colorOut, accumColor[frameIdx], tmpVar, variance, filteredVar, gBuffer, cam, 0);
+    std::swap(colorOut, accumColor[frameIdx]);
+    std::swap(tmpVar, variance);
+    filterVariance();
+    waveletFilter.filter(colorOut, accumColor[frameIdx], tmpVar, variance, filteredVar, gBuffer, cam, 1);
+    std::swap(tmpVar, variance);
+    for (int lv = 2; lv <= 4; lv++) {
+        filterVariance();
+        waveletFilter.filter(tmpColor, colorOut, tmpVar, variance, filteredVar, gBuffer, cam, lv);
+        std::swap(tmpColor, colorOut);
+        std::swap(tmpVar, variance);
+    }
+}
+inline void SpatioTemporalFilter::nextFrame() { frameIdx ^= 1; }  // :560
+#endif  // RADISH_SHIM_WITH_DENOISER
 #endif

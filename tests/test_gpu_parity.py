@@ -550,6 +550,87 @@ def test_scene_file_renders_bit_exact(gpu_ctx, tmp_path):
     assert_bit_equal(dd.cpu().numpy(), ref, "scene file: pathTraceDirect")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Denoisers (src/denoiser.cu): every kernel and both filter classes, bit-exact against the oracle on a rendered G-buffer
+# ---------------------------------------------------------------------------------------------------------------------
+def test_denoisers_bit_exact(gpu_ctx):
+    from oracle import pyoracle
+    from radish_pt_amd import api, hostlib, scenes
+
+    torch = _torch()
+    sd = scenes.teapots(segments=12, bands=8, grid=2, emissive_grid=(4, 8))
+    gpu_ctx.set_partition(0, 1, 64)
+    gpu_ctx.upload_scene(sd)
+    o = _oracle(sd)
+    W, H = 70, 45  # not multiples of the 32x8 workgroup footprint
+    n = W * H
+    cams = [hostlib.make_camera(W, H, eye=(0.3 + 0.07 * f, 1.9, 7.4), rotation=(-91.5, -11.0, 0.0), fovy=19.0) for f in range(3)]
+    gb_ref = pyoracle.GBufferHost(W, H)
+    gb = api.GBuffer()
+    gb.create(W, H)
+    dev = api.DevScene()
+    dev.ctx = gpu_ctx
+    scene = api.Scene.__new__(api.Scene)  # the mirror's globals: State.scene.devScene.ctx / .camera
+    scene.devScene, scene.camera, scene.data = dev, cams[0], sd
+    api.State.scene = scene
+    rng = np.random.default_rng(2)
+    eaw = api.LeveledEAWFilter()
+    eaw.create(W, H, 5)
+    stf = api.SpatioTemporalFilter()
+    stf.create(W, H, 5)
+    # the oracle's copy of SpatioTemporalFilter's state
+    accC = [np.zeros((n, 3), np.float32) for _ in range(2)]
+    accM = [np.zeros((n, 3), np.float32) for _ in range(2)]
+    first, fidx = True, 0
+    for f, cam in enumerate(cams):
+        scene.camera = cam
+        o.gbuffer_render(cam, gb_ref)
+        gb.render(dev, cam)
+        noisy = (rng.random((n, 3)).astype(np.float32) ** 2) * 2.0
+        noisy[rng.integers(0, n, 5)] = 40.0  # fireflies
+        d_noisy = _dev(noisy)
+        # ---- LeveledEAWFilter::filter: five a-trous levels (denoiser.cu:419-434) ----
+        ref = pyoracle.denoise_eaw(noisy, gb_ref, cam, 64.0, 0.2, 1.0, 0)
+        for lv in (1, 2, 3, 4):
+            ref = pyoracle.denoise_eaw(ref, gb_ref, cam, 64.0, 0.2, 1.0, lv)
+        out = eaw.filter(torch.zeros(n, 3, device="cuda"), d_noisy, gb, cam)
+        assert_bit_equal(out.cpu().numpy(), ref, f"LeveledEAWFilter frame {f}")
+        assert np.abs(ref - noisy).max() > 0.1  # it really filtered
+        # ---- SpatioTemporalFilter::filter (denoiser.cu:525-558) ----
+        accC[fidx], accM[fidx] = pyoracle.denoise_temporal_accumulate(accC[fidx ^ 1], accM[fidx ^ 1], noisy, gb_ref, first)
+        first = False
+        var = pyoracle.denoise_estimate_variance(accM[fidx], W, H)
+        fvar = pyoracle.denoise_filter_variance(var, W, H)
+        colorOut, tmpVar = pyoracle.denoise_svgf(accC[fidx], var, fvar, gb_ref, cam, 4.0, 128.0, 1.0, 0)
+        colorOut, accC[fidx] = accC[fidx], colorOut  # std::swap(colorOut, accumColor[frameIdx])
+        var = tmpVar
+        fvar = pyoracle.denoise_filter_variance(var, W, H)
+        colorOut, var = pyoracle.denoise_svgf(accC[fidx], var, fvar, gb_ref, cam, 4.0, 128.0, 1.0, 1)
+        for lv in (2, 3, 4):
+            fvar = pyoracle.denoise_filter_variance(var, W, H)
+            colorOut, var = pyoracle.denoise_svgf(colorOut, var, fvar, gb_ref, cam, 4.0, 128.0, 1.0, lv)
+        got = stf.filter(torch.zeros(n, 3, device="cuda"), d_noisy, gb, cam)
+        assert_bit_equal(got.cpu().numpy(), colorOut, f"SpatioTemporalFilter frame {f}")
+        assert_bit_equal(stf.variance.cpu().numpy(), var, f"SVGF variance frame {f}")
+        assert_bit_equal(stf.accumColor[stf.frameIdx].cpu().numpy(), accC[fidx], f"accumColor frame {f}")
+        assert np.isfinite(colorOut).all()
+        stf.nextFrame()
+        fidx ^= 1
+        # ---- modulateAlbedo + addImage ----
+        img = torch.from_numpy(colorOut.copy()).cuda()
+        api.modulateAlbedo(img, gb)
+        mod = pyoracle.denoise_modulate(colorOut, gb_ref)
+        assert_bit_equal(img.cpu().numpy(), mod, "modulate")
+        api.addImage(img, d_noisy, W, H)
+        assert_bit_equal(img.cpu().numpy(), pyoracle.denoise_add(mod, noisy, W, H), "addImage (two-image overload)")
+        tri = torch.zeros(n, 3, device="cuda")
+        api.addImage(tri, img, d_noisy, W, H)
+        assert_bit_equal(tri.cpu().numpy(), pyoracle.denoise_add(img.cpu().numpy(), noisy, W, H), "addImage (three-image overload)")
+        gb_ref.update(cam)
+        gb.update(cam)
+    api.State.scene = None
+
+
 def test_error_behaviour(gpu_ctx, cornell_small):
     from radish_pt_amd import api, scenes
 

@@ -617,3 +617,86 @@ def test_copy_image_to_pbo_known_bytes():
     assert mv[0].tolist() == [0, 0, 0, 0]
     assert mv[1].tolist() == [int((1 / 4) ** (1 / 2.2) * 255), 186, 0, 0]  # pixel (1, 1) of 4x2
     assert mv[3].tolist() == [0, 0, 0, 0]  # -1 % W < 0: negative colour, gamma is NaN, converts to 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Denoisers (/root/reference/src/denoiser.cu): recipes for exp / pow pinned against float64, kernels against hand values
+# ---------------------------------------------------------------------------------------------------------------------
+def test_exp_pow_recipes_accuracy():
+    from oracle import pyoracle
+
+    l = pyoracle.lib()
+    xs = np.linspace(-80.0, 5.0, 4001).astype(np.float32)
+    got = np.array([l.orc_exp(float(x)) for x in xs], np.float64)
+    assert np.max(np.abs(got - np.exp(xs.astype(np.float64))) / np.exp(xs.astype(np.float64))) < 1e-6
+    assert l.orc_exp(0.0) == 1.0 and l.orc_exp(-200.0) == 0.0 and np.isnan(l.orc_exp(float("nan")))
+    x = np.linspace(0.05, 1.0, 1001).astype(np.float32)
+    for y in (128.0, 0.2, 2.0):
+        got = np.array([l.orc_pow(float(v), y) for v in x], np.float64)
+        ref = np.power(x.astype(np.float64), y)
+        m = ref > 1e-30
+        assert np.max(np.abs(got[m] - ref[m]) / ref[m]) < 2e-5, y
+    assert l.orc_pow(0.0, 128.0) == 0.0 and l.orc_pow(1.0, 128.0) == 1.0
+
+
+def _flat_gbuffer(W, H, prim=0):
+    from oracle import pyoracle
+
+    gb = pyoracle.GBufferHost(W, H)
+    gb.albedo[:] = 0.5
+    for k in range(2):
+        gb.normal[k][:] = (0, 0, 1)
+        gb.depth[k][:] = 2.0
+        gb.primId[k][:] = prim
+    gb.motion[:] = np.arange(W * H, dtype=np.int32)
+    return gb
+
+
+def test_denoise_kernels_known_answers():
+    from oracle import pyoracle
+    from radish_pt_amd import hostlib
+
+    W, H = 9, 7
+    n = W * H
+    cam = hostlib.make_camera(W, H, eye=(0, 0, 5), rotation=(-90, 0, 0), fovy=20.0)
+    gb = _flat_gbuffer(W, H)
+    const = np.full((n, 3), 0.25, np.float32)
+    # a constant image is a fixed point of the EAW filter (weights normalise), up to the rounding of sum / weightSum
+    out = pyoracle.denoise_eaw(const, gb, cam, 64.0, 0.2, 1.0, 0)
+    assert np.allclose(out, 0.25, rtol=0, atol=1e-7)
+    # a pixel whose id differs from all its neighbours keeps its colour; miss / light pixels are copied
+    gb2 = _flat_gbuffer(W, H)
+    gb2.primId[0][3 * W + 4] = 7
+    gb2.primId[0][0] = -1
+    img = np.random.default_rng(0).random((n, 3)).astype(np.float32)
+    out = pyoracle.denoise_eaw(img, gb2, cam, 64.0, 0.2, 1.0, 1)
+    assert np.allclose(out[3 * W + 4], img[3 * W + 4], rtol=3e-7, atol=0)  # (c*w)/w: only itself in the sum
+    assert np.array_equal(out[0], img[0])
+    # temporal accumulation: first frame copies colour and (lum, lum^2, 0); then mix with alpha 0.2 and count frames
+    col = np.full((n, 3), 0.5, np.float32)
+    c1, m1 = pyoracle.denoise_temporal_accumulate(np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), col, gb, True)
+    lum = np.float32(0.2126) * np.float32(0.5) + np.float32(0.7152) * np.float32(0.5) + np.float32(0.0722) * np.float32(0.5)
+    assert np.array_equal(c1, col) and np.allclose(m1[:, 0], lum) and np.allclose(m1[:, 1], lum * lum) and (m1[:, 2] == 0).all()
+    col2 = np.full((n, 3), 1.0, np.float32)
+    c2, m2 = pyoracle.denoise_temporal_accumulate(c1, m1, col2, gb, False)
+    assert np.allclose(c2, 0.5 * 0.8 + 1.0 * 0.2, atol=1e-7) and (m2[:, 2] == 1).all()
+    gb.motion[5] = -1
+    c3, m3 = pyoracle.denoise_temporal_accumulate(c1, m1, col2, gb, False)
+    assert np.array_equal(c3[5], col2[5]) and m3[5, 2] == 0  # no history
+    # variance: temporal (count > 3.5) = m.y - m.x^2, else the 3x3 spatial mean of the moments
+    mom = np.zeros((n, 3), np.float32)
+    mom[:, 0], mom[:, 1], mom[:, 2] = 0.5, 0.5, 4.0
+    assert np.allclose(pyoracle.denoise_estimate_variance(mom, W, H), 0.25)
+    mom[:, 2] = 0.0
+    mom[:, 0] = np.arange(n, dtype=np.float32) % W  # x coordinate
+    mom[:, 1] = mom[:, 0] ** 2
+    v = pyoracle.denoise_estimate_variance(mom, W, H).reshape(H, W)
+    assert np.isclose(v[3, 4], 2.0 / 3.0, atol=1e-5)  # var of {3,4,5}
+    assert np.isclose(v[3, 0], 0.25, atol=1e-6)        # border: {0,1} only
+    fv = pyoracle.denoise_filter_variance(np.ones(n, np.float32), W, H)
+    assert np.allclose(fv, 1.0, atol=1e-6)
+    # modulate multiplies by max(albedo, 0); add adds
+    gb.albedo[0] = (-1.0, 2.0, 0.5)
+    mo = pyoracle.denoise_modulate(img, gb)
+    assert np.array_equal(mo[0], img[0] * np.array([0, 2.0, 0.5], np.float32)) and np.array_equal(mo[1], img[1] * np.float32(0.5))
+    assert np.array_equal(pyoracle.denoise_add(img, mo, W, H), img + mo)
