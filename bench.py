@@ -218,7 +218,7 @@ def main():
         out = {
             "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong",  # the frame (total work) is fixed; per-GPU work shrinks with N
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} stand-in ({sd.num_prims} tris), {W}x{H}, {depth} bounces, 1 spp/frame, "
                                    f"pathTrace ({args.mode}), tile-partitioned x{world}",

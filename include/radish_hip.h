@@ -92,7 +92,9 @@ typedef struct rdh_counters {
 #define RDH_PT_SORT_MATERIAL 2u/* wavefront only: bin hits by BSDF type before shading                      */
 #define RDH_PT_COUNT 4u        /* maintain rdh_counters (adds atomics; leave off when timing)               */
 #define RDH_PT_PERSISTENT 16u  /* one persistent launch: per-lane state machine with lane refill (kernels_persist.h) */
-#define RDH_PT_MEGA_GBUFFER 64u /* rdh_gbuffer_render only: the one-lane-per-pixel kernel instead of the persistent one      */
+#define RDH_PT_ONE_LANE_PER_PIXEL 64u /* rdh_gbuffer_render: the one-lane-per-pixel kernel (k_gbuffer) instead of the persistent
+                                         lane-refill one (k_gbuffer_persistent)                                              */
+#define RDH_PT_MEGA_GBUFFER RDH_PT_ONE_LANE_PER_PIXEL
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read            */

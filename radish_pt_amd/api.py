@@ -29,7 +29,8 @@ HIP_LIB_PATH = os.environ.get("RADISH_HIP_LIB") or os.path.join(_HERE, "csrc", "
 RDH_PT_MEGAKERNEL, RDH_PT_WAVEFRONT, RDH_PT_SORT_MATERIAL, RDH_PT_COUNT, RDH_PT_PROFILE = 0, 1, 2, 4, 8
 RDH_PT_PERSISTENT = 16
 RDH_PT_NO_SCHEDULE = 32
-RDH_PT_MEGA_GBUFFER = 64
+RDH_PT_ONE_LANE_PER_PIXEL = 64
+RDH_PT_MEGA_GBUFFER = RDH_PT_ONE_LANE_PER_PIXEL
 SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12
 
 # Every symbol include/radish_hip.h declares (tests check that the library exports all of them).

@@ -589,7 +589,7 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
     DCamera last = toDeviceCamera(gb->lastCam);
     GBufPtrs p{gb->albedo, gb->normal[gb->frameIdx], gb->motion, gb->depth[gb->frameIdx], gb->primId[gb->frameIdx],
                gb->width, gb->height};
-    if (flags & RDH_PT_MEGA_GBUFFER) {  // one lane per pixel for the whole launch (the reference's structure)
+    if (flags & RDH_PT_ONE_LANE_PER_PIXEL) {  // one lane per pixel for the whole launch (the reference's structure)
         timeBegin(c);
         if (flags & RDH_PT_COUNT)
             hipLaunchKernelGGL(k_gbuffer<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p);
@@ -692,6 +692,9 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
         grid1 = ((work + 7u) / 8u) * 8u;
     }
     timeBegin(c);
+    // One lane per pixel: a persistent lane-refill version of this pass (as for the G-buffer) was built and measured slower
+    // (3.21 ms against 2.90 ms on the teapots config): the 32-candidate RIS dominates, runs at full wave width here and at
+    // 32-48 lanes per batch there, and the state machine's 146 VGPRs cost two of this kernel's five waves per SIMD.
     if (flags & RDH_PT_COUNT)
         hipLaunchKernelGGL(k_restir_pass1<true>, dim3(grid1), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
     else
@@ -832,6 +835,7 @@ int rdh_copy_image_to_pbo(rdh_ctx *c, void *d_pbo, const void *d_image, int widt
 }
 
 // ---- denoisers (src/denoiser.cu) -----------------------------------------------------------------------------------------
+extern "C++" {
 namespace {
 int denoiseGB(rdh_ctx *c, const rdh_gbuffer *gb, DenoiseGB &d, const char *what) {
     if (!gb || !gb->albedo || !gb->motion || gb->frameIdx < 0 || gb->frameIdx > 1 || gb->width <= 0 || gb->height <= 0)
@@ -845,6 +849,7 @@ int denoiseGB(rdh_ctx *c, const rdh_gbuffer *gb, DenoiseGB &d, const char *what)
 }
 dim3 denoiseGrid(int w, int h) { return dim3((unsigned)((w + 31) / 32), (unsigned)((h + 7) / 8)); }
 }  // namespace
+}  // extern "C++"
 
 int rdh_denoise_eaw(rdh_ctx *c, float *d_colorOut, const float *d_colorIn, const rdh_gbuffer *gb, const void *camera196,
                     float sigLumin, float sigNormal, float sigDepth, int level) {

@@ -209,15 +209,22 @@ def test_restir_sequence_bit_exact(gpu_ctx, reuse, faithful):
         assert_bit_equal(gb.albedo.cpu().numpy(), gb_ref.albedo, "gbuffer albedo")
         assert_bit_equal(gb.normal[cur].cpu().numpy(), gb_ref.normal[cur], "gbuffer normal")
         assert_bit_equal(gb.depth[cur].cpu().numpy(), gb_ref.depth[cur], "gbuffer depth")
+        before = o.stats()
         o.restir_direct(cam, ref_img, 0, 40 + f, res[0], res[1], res[2], gb_ref, f == 0, reuse, faithful)
+        after = o.stats()
         res[0], res[1] = res[1], res[0]  # std::swap(directReservoir, lastDirectReservoir)
         gpu_ctx.set_camera(cam)
-        gpu_ctx.restir_direct(img, 0, 40 + f, gb.c_struct(cam), reuse, faithful_ris=faithful)
+        gpu_ctx.counters_reset()
+        gpu_ctx.restir_direct(img, 0, 40 + f, gb.c_struct(cam), reuse, faithful_ris=faithful,
+                              flags=api.RDH_PT_COUNT)
         got = img.cpu().numpy()
         assert _frac_outside(got, ref_img) == 0.0
         assert_bit_equal(got, ref_img, f"ReSTIR frame {f} reuse={reuse}")
         last = gpu_ctx.restir_read(1)  # what this frame wrote is now `last`
         assert last.tobytes() == res[1].tobytes(), f"reservoirs frame {f}"
+        ct = gpu_ctx.counters()
+        for k in ("closestRays", "anyRays", "nodeVisits", "triTests", "closestHits"):
+            assert ct[k] == after[k] - before[k], k
         gb_ref.update(cam)
         gb.update(cam)
     assert ref_img.max() > 0
