@@ -142,10 +142,23 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
     int k = 0;  // index of the hit the current extension ray leads to (0 = primary)
     uint32_t rngScramble = 0;
     int rngPtr = 0;
-    RaySlab rs;
-    rs.o = rs.d = rs.inv = mk3(0.f);
-    rs.cls = 0;
-    const NodeRec *nodes = s.nodes[0];
+    // the ray being walked: origin / reciprocal direction as register pairs (packed slab test), direction, slab-test class
+    RaySlabPk rp;
+    rp.oxy = rp.ozw = rp.ixy = rp.izw = f2v{0.f, 0.f};
+    v3 rayD = mk3(0.f);
+    int rayCls = 0;
+    auto slab = [&]() {  // the RaySlab view of it (same registers)
+        RaySlab r;
+        r.o = mk3(rp.oxy.x, rp.oxy.y, rp.ozw.x);
+        r.d = rayD;
+        r.inv = mk3(rp.ixy.x, rp.ixy.y, rp.izw.x);
+        r.cls = rayCls;
+        return r;
+    };
+    unsigned ordOfs = 0;  // byte offset of this ray's ordering inside the node allocation (layouts.h: one allocation)
+    const char *nodeBase = reinterpret_cast<const char *>(s.nodes[0]);
+    const unsigned ordStride = (unsigned)(s.bvhSize + 1) * (unsigned)sizeof(NodeRec);
+    unsigned stepMark = 0, waveSteps = 0;  // wave-uniform count of box-loop iterations: the path's cost is how many it was in flight for
     int node = end, pending = -1;
     float tmax = 0.f;
     int hitPrim = -1;
@@ -153,8 +166,14 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
     bool isShadow = false, occluded = false;
 
     auto startTrace = [&](const Ray &ray, float limit, bool shadow) {
-        rs = makeRaySlab(ray);
-        nodes = s.nodes[getMTBVHId(-ray.d)];
+        {
+            const RaySlab r = makeRaySlab(ray);
+            rp = packSlab(r);
+            rayD = r.d;
+            rayCls = r.cls;
+        }
+        ordOfs = (unsigned)getMTBVHId(-ray.d) * ordStride;
+        stepMark = waveSteps;
         node = 0;
         pending = -1;
         hitPrim = -1;
@@ -259,13 +278,13 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         PH_MARK(0);
         // ---------------- literal-class rays: traced whole by the whole wave (traverse.h, coopTraceWhole) ----------------
         {
-            unsigned long long lit = __ballot(state == PS_TRACE && rs.cls != 0 && node == 0 && pending < 0 && end != 0);
+            unsigned long long lit = __ballot(state == PS_TRACE && rayCls != 0 && node == 0 && pending < 0 && end != 0);
             while (lit) {
                 const int L = __ffsll((long long)lit) - 1;
                 lit &= lit - 1ull;
                 const bool shadowL = readlaneI(isShadow ? 1 : 0, L) != 0;
-                const NodeRec *un = readlanePtr(nodes, L);
-                const RaySlab ur = readlaneRay(rs, L);
+                const NodeRec *un = reinterpret_cast<const NodeRec *>(nodeBase + (unsigned)readlaneI((int)ordOfs, L));
+                const RaySlab ur = readlaneRay(slab(), L);
                 const float lim = readlaneF(tmax, L);
                 CoopTrace ct = shadowL ? coopTraceWhole<true>(s, un, ur, lim) : coopTraceWhole<false>(s, un, ur, lim);
                 if (lane == L) {
@@ -274,7 +293,6 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                     tmax = ct.tmax;
                     occluded = ct.found;
                     node = end;
-                    pathSteps += ct.nodes;
                     if (COUNT) {
                         ws.nodes += ct.nodes;
                         ws.tris += ct.tris;
@@ -292,25 +310,27 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
             if (nStart == 1) {
                 // a lone walker (the drain of the frame): the whole wave tests 64 boxes ahead for it (coopWalk)
                 const int L = __ffsll((long long)__ballot(walking)) - 1;
-                CoopResult cr = coopWalk(readlanePtr(nodes, L), readlaneI(node, L), end, readlaneRay(rs, L), readlaneF(tmax, L),
-                                         RD_COOP_WINDOWS);
+                CoopResult cr = coopWalk(reinterpret_cast<const NodeRec *>(nodeBase + (unsigned)readlaneI((int)ordOfs, L)),
+                                         readlaneI(node, L), end, readlaneRay(slab(), L), readlaneF(tmax, L), RD_COOP_WINDOWS);
+                waveSteps += 8u;
                 if (lane == L) {
                     node = cr.node;
                     pending = cr.pending;
-                    pathSteps += cr.visited;
                     if (COUNT) ws.nodes += cr.visited;
                 }
             } else if (nStart > 0) {
                 const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
                 do {
                     PH_COUNT(8, __ballot(walking));
+                    waveSteps++;
                     if (walking) {
-                        float4 lo = nodes[node].lo_prim;
-                        float4 hi = nodes[node].hi_next;
+                        // one VALU for the address: base (SGPRs) + 32-bit byte offset
+                        const NodeRec *rec = reinterpret_cast<const NodeRec *>(nodeBase + (ordOfs + ((unsigned)node << 5)));
+                        float4 lo = rec->lo_prim;
+                        float4 hi = rec->hi_next;
                         float boundDist;
                         if (COUNT) ws.nodes++;
-                        pathSteps++;
-                        bool boundHit = aabbFast(lo, hi, rs, boundDist);  // every walker here is of class 0 (the others were traced whole above)
+                        bool boundHit = aabbFastPk(lo, hi, rp, boundDist);  // every walker here is of class 0 (the others were traced whole above)
                         if (boundHit && boundDist < tmax) {
                             pending = __float_as_int(lo.w);
                             node++;
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                         }
                         walking = pending < 0 && node != end;
                     }
-                } while (__popcll(__ballot(walking)) >= (minWalk > 1 ? minWalk : 1));
+                } while (__popcll(ballotb(walking)) >= (minWalk > 1 ? minWalk : 1));
                 // (Requesting both successors ahead of the box test was measured and rejected: the L1 is busy ~80 % of
                 //  the launch — TCP_GATE_EN — and doubling its requests cost 7 % in the bulk and gained nothing in the
                 //  drain)
@@ -333,7 +353,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
             float dist;
             v2 bary;
             if (COUNT) ws.tris++;
-            bool hit = intersectTriangle(rs, tv.a, tv.b, tv.c, bary, dist);
+            bool hit = intersectTriangle(slab(), tv.a, tv.b, tv.c, bary, dist);
             if (hit && dist < tmax) {
                 if (isShadow) {
                     occluded = true;
@@ -349,6 +369,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         PH_MARK(3);
         // ---------------- retire finished traces ----------------
         if (state == PS_TRACE && pending < 0 && node == end) {
+            pathSteps += waveSteps - stepMark;
             if (isShadow) {
                 float nw = sNee[3][t];
                 if (!occluded && nw >= 0.f) {  // the `+=` of pathtrace.cu:201-207
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
             if (__popcll(shadeM) * 64 >= nBusy * RD_SHADE_MIN) {
                 PH_COUNT(12, shadeM);
                 if (state == PS_SHADE) {
-                    v3 rayDir = rs.d;
+                    v3 rayDir = rayD;
                     bool terminate = true;  // set false once a shadow or extension ray is started
                     do {
                         if (hitPrim == -1) {  // miss: pathtrace.cu:169-172 (primary), :232-247 (later)

@@ -60,7 +60,7 @@ struct Counters {
 };
 
 struct DScene {
-    const NodeRec *nodes[6];
+    const NodeRec *nodes[6];  // one allocation: nodes[k] = nodes[0] + k * (bvhSize + 1)
     const TriRec *tris;
     const AttrRec *attrs;
     const MatRec *mats;

@@ -175,6 +175,35 @@ RD_DEV bool aabbFast(float4 lo, float4 hi, const RaySlab &r, float &tMin) {
     return overlap & (tMax >= 0.f) & (tMax >= tMin);
 }
 
+// aabbFast with the twelve subtract / multiply of the slab test as four packed pairs (v_pk_add_f32 / v_pk_mul_f32 process
+// two binary32 lanes per instruction, each IEEE-exact, so the bits are those of aabbFast); the ray's origin and reciprocal
+// direction are kept as register pairs.  The .w halves of the records (int bits) ride along and are never read.
+typedef float f2v __attribute__((ext_vector_type(2)));
+struct RaySlabPk {
+    f2v oxy, ozw, ixy, izw;  // origin.xy, {origin.z, 0}, inv.xy, {inv.z, 0}
+};
+RD_DEV RaySlabPk packSlab(const RaySlab &r) {
+    RaySlabPk p;
+    p.oxy = f2v{r.o.x, r.o.y};
+    p.ozw = f2v{r.o.z, 0.f};
+    p.ixy = f2v{r.inv.x, r.inv.y};
+    p.izw = f2v{r.inv.z, 0.f};
+    return p;
+}
+RD_DEV bool aabbFastPk(float4 lo, float4 hi, const RaySlabPk &r, float &tMin) {
+    const f2v t1xy = (f2v{lo.x, lo.y} - r.oxy) * r.ixy, t1zw = (f2v{lo.z, lo.w} - r.ozw) * r.izw;
+    const f2v t2xy = (f2v{hi.x, hi.y} - r.oxy) * r.ixy, t2zw = (f2v{hi.z, hi.w} - r.ozw) * r.izw;
+    float nx = __builtin_fminf(t1xy.x, t2xy.x), ny = __builtin_fminf(t1xy.y, t2xy.y), nz = __builtin_fminf(t1zw.x, t2zw.x);
+    float fx = __builtin_fmaxf(t1xy.x, t2xy.x), fy = __builtin_fmaxf(t1xy.y, t2xy.y), fz = __builtin_fmaxf(t1zw.x, t2zw.x);
+    float dx = fx - nx, dy = fy - ny, dz = fz - nz;
+    float yz = fz - ny, zx = fx - nz, xy = fy - nx;
+    bool overlap = (dy + dz > yz) & (dz + dx > zx) & (dx + dy > xy);
+    tMin = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+    float tMax = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    return overlap & (tMax >= 0.f) & (tMax >= tMin);
+}
+RD_DEV unsigned long long ballotb(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // no bool -> int -> compare round trip
+
 // Out-of-line wrapper for the literal test: only rays with an axis-parallel, tiny or non-finite direction component
 // come here, and inlining it makes the compiler fuse it with the fast path of the hot loop.  Everything by value (an
 // address-taken RaySlab would be forced into scratch memory).  Returns {hit ? 1 : 0, tMin}.

@@ -393,11 +393,14 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
     c->ds.envTex = d->envMapTexId;
     c->ds.envSamplerLength = d->envMapSamplerLength;
 
-    std::vector<NodeRec> nodes(S + 1);  // +1: a readable pad record at index S (speculative next-node loads)
-    nodes[S].lo_prim = make_float4(0.f, 0.f, 0.f, asFloat(-1));
-    nodes[S].hi_next = make_float4(0.f, 0.f, 0.f, asFloat(S));
+    // The six orderings live in ONE allocation, (S + 1) records each (+1: a readable pad record at index S for speculative
+    // next-node loads), so that a kernel can address any record as base + 32-bit byte offset (saddr form, one VALU) instead
+    // of a per-lane 64-bit pointer; nodes[k] point into it.
+    if ((size_t)6 * (S + 1) * sizeof(NodeRec) >= 0xffffffffull) return fail(c, RDH_ERR_ARGS, "scene too large: %d BVH nodes", S);
+    std::vector<NodeRec> nodes((size_t)6 * (S + 1));
     for (int k = 0; k < 6; k++) {
         const int32_t *src = d->bvhNodes[k];
+        NodeRec *dst = nodes.data() + (size_t)k * (S + 1);
         for (int i = 0; i < S; i++) {
             int prim = src[3 * i], box = src[3 * i + 1], next = src[3 * i + 2];
             if (box < 0 || box >= S || next < 0 || next > S || prim < -1 || prim >= N || next <= i)
@@ -405,11 +408,14 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
             const float *b = d->boundingBoxes + 6 * (size_t)box;
             for (int q = 0; q < 6; q++)  // aabbFast (device/traverse.h) assumes finite, moderately sized coordinates
                 if (!(std::fabs(b[q]) < 1e30f)) return fail(c, RDH_ERR_ARGS, "boundingBoxes[%d] is not finite / exceeds 1e30", box);
-            nodes[i].lo_prim = make_float4(b[0], b[1], b[2], asFloat(prim));
-            nodes[i].hi_next = make_float4(b[3], b[4], b[5], asFloat(next));
+            dst[i].lo_prim = make_float4(b[0], b[1], b[2], asFloat(prim));
+            dst[i].hi_next = make_float4(b[3], b[4], b[5], asFloat(next));
         }
-        if ((rc = uploadVec(c, nodes, &c->ds.nodes[k]))) return rc;
+        dst[S].lo_prim = make_float4(0.f, 0.f, 0.f, asFloat(-1));
+        dst[S].hi_next = make_float4(0.f, 0.f, 0.f, asFloat(S));
     }
+    if ((rc = uploadVec(c, nodes, &c->ds.nodes[0]))) return rc;
+    for (int k = 1; k < 6; k++) c->ds.nodes[k] = c->ds.nodes[0] + (size_t)k * (S + 1);
 
     std::vector<LightRec> lights(d->numLights);
     for (int i = 0; i < d->numLights; i++) {

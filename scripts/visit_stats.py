@@ -78,3 +78,6 @@ for K in (64, 128, 256, 512):
         hot = np.argsort(-pri, kind="stable")[:K]
         cov += h6[k][hot].sum()
     print(f"parent-area heuristic, {K:4d} nodes per ordering: {100 * cov / total:5.1f} % of visits")
+for K in (32, 64, 128, 256, 512, 1024):
+    cov = sum(h6[k][:K].sum() for k in range(6))
+    print(f"first {K:5d} records of each ordering (depth-first prefix): {100 * cov / total:5.1f} % of visits")
