@@ -238,9 +238,10 @@ def main():
             ref_d = np.zeros((W * H, 3), np.float32)
             ref_i = np.zeros((W * H, 3), np.float32)
             stride = 1  # the whole frame: ~6 s of single-thread CPU work, and a full-frame parity check for free
-            if hasattr(os, "sched_setaffinity"):
+            full_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+            if full_affinity is not None:
                 try:
-                    os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+                    os.sched_setaffinity(0, {sorted(full_affinity)[0]})
                 except OSError:
                     pass
             tc = time.perf_counter()
@@ -253,6 +254,31 @@ def main():
                 "sample": f"oracle pathTrace on every pixel (stride {stride}) of the same {W}x{H} depth-{depth} frame "
                           f"(looper {Wm}): {cpu_rays} rays in {cpu_s:.1f} s",
             }
+            # secondary figure: the same frame on all host cores of this process's share, one oracle handle per
+            # thread, pixels dealt round-robin (the ctypes call releases the GIL)
+            if full_affinity is not None:
+                try:
+                    os.sched_setaffinity(0, full_affinity)
+                except OSError:
+                    pass
+            import threading
+
+            nthreads = max(1, min(16, len(full_affinity) if full_affinity else (os.cpu_count() or 1)))
+            if nthreads > 1:
+                handles = [pyoracle.OracleScene(sd) for _ in range(nthreads)]
+                td, ti = np.zeros((W * H, 3), np.float32), np.zeros((W * H, 3), np.float32)
+                threads = [threading.Thread(target=handles[t].path_trace, args=(cam, td, ti, 0, Wm, depth),
+                                            kwargs={"pix": (t, W * H, nthreads)}) for t in range(nthreads)]
+                tc = time.perf_counter()
+                for th in threads:
+                    th.start()
+                for th in threads:
+                    th.join()
+                par_s = time.perf_counter() - tc
+                par_rays = sum(h.stats()["closestRays"] + h.stats()["anyRays"] for h in handles)
+                out["cpu_baseline"]["all_cores"] = {"value": round(par_rays / par_s / 1e6, 4), "unit": "Mrays/s", "cores": nthreads,
+                                                    "bit_equal_to_one_thread": bool(np.array_equal(td.view(np.uint32), ref_d.view(np.uint32))
+                                                                                    and np.array_equal(ti.view(np.uint32), ref_i.view(np.uint32)))}
             # parity spot check on the timed configuration: the sampled pixels must equal the GPU frame bit for bit
             with torch.cuda.stream(slots[0].stream):
                 ctx.path_trace(direct, indirect, 0, Wm, depth, flags)
