@@ -209,7 +209,7 @@ def main():
         achieved = (alg_bytes / launches) / (trace_ms / launches * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path) and world == 1 and F == 1:  # the PMC figure is per launch of the one-GPU workload
             try:
                 with open(pmc_path) as fh:
                     traffic = json.load(fh).get(f"{args.scene}_{args.mode}_{W}x{H}_d{depth}_bytes_per_launch")
