@@ -54,7 +54,13 @@ constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
 constexpr int kCostBuckets = 64;
 // 256 threads, <= 64 VGPRs: fits beside a chip full of persistent waves (3 x 131 VGPRs per SIMD leave room for one more
 // small wave), so with two frames in flight the next frame's schedule does not queue behind the current frame's tail.
-__global__ __launch_bounds__(256) void k_persist_schedule(unsigned *__restrict__ cost, int *__restrict__ order, int n) {
+// `ema`: running estimate of each block's cost over the frames so far (the per-launch figure is ONE sample of the longest of
+// 64 random paths — noisy; blocks differ systematically by what they look at).  ema' = (RD_EMA_KEEP * ema + cost) / (RD_EMA_KEEP + 1).
+#ifndef RD_EMA_KEEP
+#define RD_EMA_KEEP 7
+#endif
+__global__ __launch_bounds__(256) void k_persist_schedule(unsigned *__restrict__ cost, unsigned *__restrict__ ema,
+                                                          int *__restrict__ order, int n) {
     __shared__ int hist[kCostBuckets], base[kCostBuckets];
     const int t = int(threadIdx.x);
     if (t < kCostBuckets) hist[t] = 0;
@@ -69,7 +75,11 @@ __global__ __launch_bounds__(256) void k_persist_schedule(unsigned *__restrict__
         if (b > kCostBuckets - 1) b = kCostBuckets - 1;
         return kCostBuckets - 1 - b;
     };
-    for (int i = t; i < n; i += 256) atomicAdd(&hist[bucketOf(cost[i])], 1);
+    for (int i = t; i < n; i += 256) {
+        const unsigned e = ema[i] == 0u ? cost[i] : (RD_EMA_KEEP * ema[i] + cost[i] + RD_EMA_KEEP / 2) / (RD_EMA_KEEP + 1);
+        ema[i] = e;
+        atomicAdd(&hist[bucketOf(e)], 1);
+    }
     __syncthreads();
     if (t == 0) {
         int acc = 0;
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(256) void k_persist_schedule(unsigned *__restrict__
     }
     __syncthreads();
     for (int i = t; i < n; i += 256) {  // order inside a bucket is arrival order: ties are equally expensive
-        int pos = atomicAdd(&base[bucketOf(cost[i])], 1);
+        int pos = atomicAdd(&base[bucketOf(ema[i])], 1);
         order[pos] = i;
     }
     __syncthreads();

@@ -41,6 +41,7 @@ struct rdh_ctx {
     unsigned persistGrid = 0;
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned *blockCost = nullptr;  // per-8x8-block cost of the previous persistent launch (k_persist_schedule)
+    unsigned *blockEma = nullptr;   // running mean of it over the launches so far
     int *blockOrder = nullptr;
     int costBlocks = 0;             // blocks the two arrays are sized / valid for
     bool orderValid = false;
@@ -291,6 +292,7 @@ void rdh_destroy(rdh_ctx *c) {
     if (c->dCounters) hipFree(c->dCounters);
     if (c->dPersist) hipFree(c->dPersist);
     if (c->blockCost) hipFree(c->blockCost);
+    if (c->blockEma) hipFree(c->blockEma);
     if (c->blockOrder) hipFree(c->blockOrder);
     if (c->evStart) hipEventDestroy(c->evStart);
     if (c->evStop) hipEventDestroy(c->evStop);
@@ -517,10 +519,14 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         // longest-paths-first schedule from the previous launch's per-block costs (same partition and resolution only)
         if (c->costBlocks != pm.numBlocks) {
             if (c->blockCost) hipFree(c->blockCost);
+            if (c->blockEma) hipFree(c->blockEma);
+            c->blockEma = nullptr;
             if (c->blockOrder) hipFree(c->blockOrder);
             c->blockCost = nullptr;
             c->blockOrder = nullptr;
             HIP_TRY(c, hipMalloc((void **)&c->blockCost, sizeof(unsigned) * (size_t)pm.numBlocks));
+            HIP_TRY(c, hipMalloc((void **)&c->blockEma, sizeof(unsigned) * (size_t)pm.numBlocks));
+            HIP_TRY(c, hipMemsetAsync(c->blockEma, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
             HIP_TRY(c, hipMalloc((void **)&c->blockOrder, sizeof(int) * (size_t)pm.numBlocks));
             HIP_TRY(c, hipMemsetAsync(c->blockCost, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
             c->costBlocks = pm.numBlocks;
@@ -529,7 +535,7 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         timeBegin(c);
         const bool useOrder = c->orderValid && !(flags & RDH_PT_NO_SCHEDULE);
         if (useOrder)
-            hipLaunchKernelGGL(k_persist_schedule, dim3(1), dim3(256), 0, c->stream, c->blockCost, c->blockOrder, pm.numBlocks);
+            hipLaunchKernelGGL(k_persist_schedule, dim3(1), dim3(256), 0, c->stream, c->blockCost, c->blockEma, c->blockOrder, pm.numBlocks);
         else
             HIP_TRY(c, hipMemsetAsync(c->blockCost, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, sizeof(PersistCounters), c->stream));
