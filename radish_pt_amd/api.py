@@ -230,7 +230,7 @@ class Context:
         self.check(lib().rdh_untile(self.h, gathered.data_ptr(), frame.data_ptr()))
 
     # ---- hot path ----
-    def path_trace(self, direct, indirect, iter, looper, max_depth, flags=RDH_PT_MEGAKERNEL):
+    def path_trace(self, direct, indirect, iter, looper, max_depth, flags=RDH_PT_PERSISTENT):
         self.check(lib().rdh_path_trace(self.h, direct.data_ptr(), indirect.data_ptr(), iter, looper, max_depth, flags))
 
     def path_trace_direct(self, direct, iter, looper, flags=0):
@@ -352,7 +352,7 @@ class Settings:  # src/common.h:50-66, defaults src/common.cpp:3-15
     reservoirReuse = ReservoirReuse.Temporal
     accumulate = False
     # knobs that exist only here (not in the reference)
-    ptFlags = RDH_PT_MEGAKERNEL
+    ptFlags = RDH_PT_PERSISTENT  # the fastest pathTrace kernel (RDH_PT_MEGAKERNEL = the reference's one-lane-per-pixel structure)
     restirNumSpatial = 5      # src/restir.cu:87
     restirRISCount = 32       # RESERVOIR_SIZE, src/restir.h:9
     restirTemporalClamp = 20  # src/restir.cu:168

@@ -94,7 +94,7 @@ inline void pathTrace(glm::vec3 *directIllum, glm::vec3 *indirectIllum, int iter
     rdh_ctx *c = radish_shim::ctx();
     RADISH_CHECK(rdh_set_camera(c, &State::scene->camera), "pathTrace");
     RADISH_CHECK(rdh_path_trace(c, reinterpret_cast<float *>(directIllum), reinterpret_cast<float *>(indirectIllum), iter,
-                                State::looper, Settings::traceDepth, RDH_PT_WAVEFRONT),
+                                State::looper, Settings::traceDepth, RDH_PT_PERSISTENT),
                  "pathTrace");
     RADISH_CHECK(rdh_synchronize(c), "pathTrace");
     float ms = 0.f;

@@ -638,6 +638,71 @@ def test_denoisers_bit_exact(gpu_ctx):
     api.State.scene = None
 
 
+def test_mirror_frame_loop_like_runCuda():
+    """The reference's frame loop (`runCuda`, /root/reference/src/main.cpp:163-202) written against the Python mirror of its
+    API — gBuffer.render, ReSTIRDirect / pathTraceDirect / pathTrace with the global State.looper, copyImageToPBO,
+    gBuffer.update — with an animated camera; every frame's image and RGBA8 preview equal the oracle driven the same way."""
+    from oracle import pyoracle
+    from radish_pt_amd import api, hostlib, layouts as L, scenes
+
+    torch = _torch()
+    sd = scenes.teapots(segments=12, bands=8, grid=2, emissive_grid=(4, 8))
+    W, H = 56, 40
+    n = W * H
+
+    def camera_at(f):  # Settings::animateCamera: the eye moves, then Camera::update
+        return hostlib.make_camera(W, H, eye=(0.3 + 0.06 * np.cos(0.4 * f), 1.9, 7.4 + 0.06 * np.sin(0.4 * f)),
+                                   rotation=(-91.5, -11.0, 0.0), fovy=19.0)
+
+    api.State.looper = 5
+    api.State.scene = api.Scene(sd, camera_at(0))
+    api.Settings.traceDepth = 3
+    api.Settings.reservoirReuse = api.ReservoirReuse.TemporalSpatial
+    api.Settings.ptFlags = api.RDH_PT_PERSISTENT
+    o = _oracle(sd)
+    looper = 5
+    try:
+        api.pathTraceInit()
+        api.ReSTIRInit()
+        gb, gb_ref = api.GBuffer(), pyoracle.GBufferHost(W, H)
+        gb.create(W, H)
+        direct, indirect = torch.zeros(n, 3, device="cuda"), torch.zeros(n, 3, device="cuda")
+        pbo = torch.zeros(n, 4, dtype=torch.uint8, device="cuda")
+        res = [np.zeros(n, L.RESERVOIR_DTYPE) for _ in range(3)]
+        ref_d, ref_i = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        for f in range(4):
+            cam = camera_at(f)
+            api.State.scene.camera = cam
+            iteration = 0  # camChanged: runCuda resets it every frame (SURVEY Q18)
+            gb.render(api.State.scene.devScene, cam)
+            o.gbuffer_render(cam, gb_ref)
+            mode = ("restir", "direct", "pt", "restir")[f]
+            if mode == "restir":
+                api.ReSTIRDirect(direct, iteration, gb)
+                o.restir_direct(cam, ref_d, iteration, looper, res[0], res[1], res[2], gb_ref, f == 0, 3, 1)
+                res[0], res[1] = res[1], res[0]
+            elif mode == "direct":
+                api.pathTraceDirect(direct, iteration)
+                o.path_trace_direct(cam, ref_d, iteration, looper)
+            else:
+                api.pathTrace(direct, indirect, iteration)
+                o.path_trace(cam, ref_d, ref_i, iteration, looper, 3)
+                assert_bit_equal(indirect.cpu().numpy(), ref_i, f"frame {f} indirect")
+            looper = (looper + 1) % 10000
+            assert api.State.looper == looper
+            assert_bit_equal(direct.cpu().numpy(), ref_d, f"frame {f} ({mode}) direct")
+            api.copyImageToPBO(pbo, direct, W, H, api.ToneMapping.ACES)
+            assert np.array_equal(pbo.cpu().numpy(), pyoracle.copy_image_to_pbo(ref_d, W, H, 0, 2, 1.0)), f"frame {f} preview"
+            gb.update(cam)
+            gb_ref.update(cam)
+        api.ReSTIRFree()
+        api.pathTraceFree()
+    finally:
+        api.State.scene.clear()
+        api.State.scene = None
+        api.State.looper = 0
+
+
 def test_error_behaviour(gpu_ctx, cornell_small):
     from radish_pt_amd import api, scenes
 
