@@ -703,6 +703,78 @@ def test_mirror_frame_loop_like_runCuda():
         api.State.looper = 0
 
 
+@pytest.mark.parametrize("case", ["one_triangle", "no_lights", "only_lights"])
+def test_degenerate_scenes_bit_exact(gpu_ctx, case):
+    """Smallest inputs: a single triangle (BVH of one node), a scene without emitters (NEE and RIS have nothing to pick: the
+    alias table is empty), a scene of emitters only.  Every kernel family still equals the oracle."""
+    from oracle import pyoracle
+    from radish_pt_amd import api, hostlib, layouts as L, scenes
+
+    torch = _torch()
+    white = L.make_material(L.LAMBERTIAN, (0.8, 0.7, 0.6))
+    lamp = L.make_material(L.LIGHT, (6.0, 5.0, 4.0))
+    tri = np.array([[-1, 0, 0], [1, 0, 0], [0, 1.5, 0]], np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (3, 1))
+    uv = np.array([[0, 0], [1, 0], [0, 1]], np.float32)
+    if case == "one_triangle":
+        v, n, t, ids, mats = tri, nrm, uv, [0], [white]
+    else:
+        quad = np.array([[-2, -0.5, -2], [2, -0.5, -2], [2, -0.5, 2], [-2, -0.5, -2], [2, -0.5, 2], [-2, -0.5, 2]], np.float32)
+        v = np.concatenate([tri, tri + np.array([0.3, 0.2, -0.7], np.float32), quad])
+        n = np.concatenate([nrm, nrm, np.tile(np.array([0, 1, 0], np.float32), (6, 1))])
+        t = np.concatenate([uv, uv, uv, uv])
+        ids = [0, 0, 0, 0] if case == "no_lights" else [1, 1, 1, 1]
+        mats = [white, lamp]
+    sd = scenes.SceneData(case, v, n, t, np.array(ids, np.int32), np.array(mats, dtype=L.MATERIAL_DTYPE))
+    assert sd.num_lights == (0 if case != "only_lights" else 4)
+    W, H = 40, 24
+    npx = W * H
+    cam = hostlib.make_camera(W, H, eye=(0.1, 0.6, 4.0), rotation=(-90.0, 0.0, 0.0), fovy=19.5)
+    gpu_ctx.set_partition(0, 1, 64)
+    gpu_ctx.upload_scene(sd)
+    gpu_ctx.set_camera(cam)
+    o = _oracle(sd)
+    ref_d, ref_i = np.zeros((npx, 3), np.float32), np.zeros((npx, 3), np.float32)
+    for it in range(2):
+        o.path_trace(cam, ref_d, ref_i, it, 3 + it, 4)
+    st = o.stats()
+    for flags in (api.RDH_PT_PERSISTENT, api.RDH_PT_MEGAKERNEL, api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL):
+        d, i = torch.zeros(npx, 3, device="cuda"), torch.zeros(npx, 3, device="cuda")
+        gpu_ctx.counters_reset()
+        for it in range(2):
+            gpu_ctx.path_trace(d, i, it, 3 + it, 4, flags | api.RDH_PT_COUNT)
+        assert_bit_equal(d.cpu().numpy(), ref_d, f"{case} direct flags={flags}")
+        assert_bit_equal(i.cpu().numpy(), ref_i, f"{case} indirect flags={flags}")
+        assert gpu_ctx.counters() == st
+    ref = np.zeros((npx, 3), np.float32)
+    o.path_trace_direct(cam, ref, 0, 11)
+    dd = torch.zeros(npx, 3, device="cuda")
+    gpu_ctx.path_trace_direct(dd, 0, 11)
+    assert_bit_equal(dd.cpu().numpy(), ref, f"{case} pathTraceDirect")
+    gb_ref = pyoracle.GBufferHost(W, H)
+    gb = api.GBuffer()
+    gb.create(W, H)
+    dev = api.DevScene()
+    dev.ctx = gpu_ctx
+    res = [np.zeros(npx, L.RESERVOIR_DTYPE) for _ in range(3)]
+    ref_r = np.zeros((npx, 3), np.float32)
+    img = torch.zeros(npx, 3, device="cuda")
+    gpu_ctx.restir_init()
+    for f in range(2):
+        o.gbuffer_render(cam, gb_ref)
+        gb.render(dev, cam)
+        assert np.array_equal(gb.primId[gb.frameIdx].cpu().numpy(), gb_ref.primId[gb_ref.frameIdx])
+        o.restir_direct(cam, ref_r, 0, 20 + f, res[0], res[1], res[2], gb_ref, f == 0, 3, 1)
+        res[0], res[1] = res[1], res[0]
+        gpu_ctx.restir_direct(img, 0, 20 + f, gb.c_struct(cam), 3)
+        assert_bit_equal(img.cpu().numpy(), ref_r, f"{case} ReSTIR frame {f}")
+        assert gpu_ctx.restir_read(1).tobytes() == res[1].tobytes()
+        gb_ref.update(cam)
+        gb.update(cam)
+    gpu_ctx.restir_free()
+    assert (ref_d > 0).any()
+
+
 def test_error_behaviour(gpu_ctx, cornell_small):
     from radish_pt_amd import api, scenes
 
