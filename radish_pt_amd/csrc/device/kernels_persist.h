@@ -268,6 +268,23 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                         k = 0;
                         nClosest++;
                         startTrace(ray, 3.402823466e+38f, false);
+#ifndef RD_NO_ROOT_SHORTCUT
+                        // A primary ray that misses the root box is finished here and now: the walk would visit the root, miss
+                        // it, follow its link to the end of the array, and the shading step would write direct = 1
+                        // (pathtrace.cu:169-172).  More than half of the Cornell frame's pixels are such rays; taking them
+                        // through the trace / shade phases costs the wave's other lanes two phase changes each.
+                        if (rayCls == 0 && end != 0) {
+                            const NodeRec *root = reinterpret_cast<const NodeRec *>(nodeBase + ordOfs);
+                            const float4 lo = root->lo_prim, hi = root->hi_next;
+                            float boundDist;
+                            const bool boundHit = aabbFastPk(lo, hi, rp, boundDist);
+                            if (!(boundHit && boundDist < tmax) && __float_as_int(hi.w) == end) {
+                                if (COUNT) ws.nodes++;
+                                sAccD[0][t] = sAccD[1][t] = sAccD[2][t] = 1.f;
+                                finishPixel();
+                            }
+                        }
+#endif
                     }
                 }
                 slotNext += give;
