@@ -503,7 +503,7 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         return timeEnd(c, "pathTrace (wavefront)");
     }
     if (flags & RDH_PT_PERSISTENT) {
-        // one persistent launch: 4 workgroups per CU (the kernel's 116-VGPR / 24.6 KB-LDS budget), never more than
+        // one persistent launch: as many single-wave workgroups as stay resident (3 per SIMD at 165 VGPRs), never more than
         // there are 4-block groups of work
         // The grid must be fully resident: a workgroup that starts late would start its static first blocks late.
         unsigned groups = (((unsigned)(pm.numBlocks + 3) / 4 + 7u) / 8u) * 8u * 4u;  // one wave per workgroup
