@@ -52,8 +52,8 @@ constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
 // order of that figure (frames of an animation are coherent; the first frame uses plain order).  Pure scheduling:
 // which lane renders a pixel, and when, cannot change its value.
 constexpr int kCostBuckets = 64;
-// 256 threads, <= 64 VGPRs: fits beside a chip full of persistent waves (3 x 165 VGPRs per SIMD leave no room for a large wave but
-// small wave), so with two frames in flight the next frame's schedule does not queue behind the current frame's tail.
+// 256 threads, <= 64 VGPRs: as soon as one persistent wave of the previous frame has left a SIMD there is room for it, so
+// with two frames in flight the next frame's schedule does not queue behind the whole tail of the current frame.
 // `ema`: running estimate of each block's cost over the frames so far (the per-launch figure is ONE sample of the longest of
 // 64 random paths — noisy; blocks differ systematically by what they look at).  ema' = (RD_EMA_KEEP * ema + cost) / (RD_EMA_KEEP + 1).
 #ifndef RD_EMA_KEEP
