@@ -76,7 +76,7 @@ orc_scene *orc_scene_create(const orc_scene_desc *desc);
 void orc_scene_destroy(orc_scene *s);
 void orc_stats_reset(orc_scene *s);
 void orc_stats_get(const orc_scene *s, orc_stats *out);
-/* Analysis hook (scripts/visit_stats.py): while set, every box test increments visitHist[ordering*bvhSize + node]
+/* Analysis hook (tests/tools/visit_stats.py): while set, every box test increments visitHist[ordering*bvhSize + node]
  * (uint32[6*bvhSize]) and every ray adds to rayLenHist (uint64[128]: [kind][log2 bucket] counts, then visit sums;
  * kind 0 closest, 1 any).  Pass NULLs to turn it off. */
 void orc_debug_visit_hist(orc_scene *s, uint32_t *visitHist, uint64_t *rayLenHist);

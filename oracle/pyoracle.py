@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RADISH_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # RADISH_ORACLE_LIB: the sanitizer build (scripts/sanitize_cpu.sh)
+LIB_PATH = os.environ.get("RADISH_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # RADISH_ORACLE_LIB: the sanitizer build (tests/tools/sanitize_cpu.sh)
 
 RESERVOIR_BYTES = 36
 

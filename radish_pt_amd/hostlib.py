@@ -7,7 +7,7 @@ import numpy as np
 from . import layouts as L
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RADISH_HOST_LIB selects another build of the same library (scripts/sanitize_cpu.sh: the ASan/UBSan build)
+# RADISH_HOST_LIB selects another build of the same library (tests/tools/sanitize_cpu.sh: the ASan/UBSan build)
 HOST_LIB_PATH = os.environ.get("RADISH_HOST_LIB") or os.path.join(_HERE, "csrc", "libradish_host.so")
 
 _lib = None

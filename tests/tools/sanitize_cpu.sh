@@ -5,12 +5,12 @@
 # (the loader's error paths throw C++ exceptions inside the library, which the preloaded-ASan Python process cannot host).
 # GPU sanitizers are not available on the pool; the HIP library is not part of this run.
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=${TMPDIR:-/tmp}/radish_san; rm -rf $OUT; mkdir -p $OUT
 FLAGS="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer"
 g++ $FLAGS -shared -o $OUT/libradish_host.so radish_pt_amd/csrc/host/scene_build.cpp radish_pt_amd/csrc/host/scene_load.cpp -lz
 g++ $FLAGS -shared -o $OUT/liboracle.so oracle/oracle.cpp
-g++ $FLAGS -o $OUT/driver scripts/sanitize_driver.cpp radish_pt_amd/csrc/host/scene_build.cpp radish_pt_amd/csrc/host/scene_load.cpp -lz
+g++ $FLAGS -o $OUT/driver tests/tools/sanitize_driver.cpp radish_pt_amd/csrc/host/scene_build.cpp radish_pt_amd/csrc/host/scene_load.cpp -lz
 ASAN=$(g++ -print-file-name=libasan.so)
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0 RADISH_HOST_LIB=$OUT/libradish_host.so RADISH_ORACLE_LIB=$OUT/liboracle.so \
   python -m pytest tests/test_scene_loader.py tests/test_host_scene.py tests/test_oracle_kat.py tests/test_golden.py -x -q -m "not gpu" \

@@ -1,9 +1,9 @@
-// scripts/sanitize_driver.cpp — native driver for scripts/sanitize_cpu.sh: parses the scene files given on the command line
+// tests/tools/sanitize_driver.cpp — native driver for tests/tools/sanitize_cpu.sh: parses the scene files given on the command line
 // with the ASan/UBSan build of the loader (error paths included: they throw C++ exceptions inside the library, which the
 // LD_PRELOADed-ASan Python run cannot host).
 #include <cstdio>
 
-#include "../include/radish_host.h"
+#include "../../include/radish_host.h"
 
 int main(int argc, char **argv) {
     for (int i = 1; i < argc; i++) {
