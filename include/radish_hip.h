@@ -95,6 +95,8 @@ typedef struct rdh_counters {
 #define RDH_PT_ONE_LANE_PER_PIXEL 64u /* rdh_gbuffer_render: the one-lane-per-pixel kernel (k_gbuffer) instead of the persistent
                                          lane-refill one (k_gbuffer_persistent)                                              */
 #define RDH_PT_MEGA_GBUFFER RDH_PT_ONE_LANE_PER_PIXEL
+#define RDH_PT_NO_DEFER 128u   /* rdh_gbuffer_render: trace literal-class rays where they are generated (one wave each)
+                                  instead of setting them aside for the workgroup-per-ray launch (k_gbuffer_literal)   */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read            */

@@ -19,6 +19,7 @@
 // 84 B per lane, so the traversal loop runs on the walker's registers alone.
 #pragma once
 #include "kernels_pt.h"
+#include "wg_trace.h"
 
 namespace rd {
 
@@ -29,9 +30,10 @@ namespace rd {
 #define RD_PIX_REFILL_MIN 16
 #endif
 
+constexpr int kDeferCap = 256;  // rays k_gbuffer_literal takes: one per workgroup, one round
 struct PersistCounters {
     int blockHead;  // next 8x8 pixel block beyond the static first round (see k_pt_persistent)
-    int pad;
+    int deferCount;  // literal-class primary rays of the frame (k_gbuffer_find_literal); above kDeferCap none is set aside
 #ifdef RD_PERSIST_STAMPS  // diagnostic build only: when each wave started, ran out of pixels, and ended (wall clock)
     unsigned long long stamp[3][4096];
 #endif
@@ -41,6 +43,7 @@ struct PersistCounters {
     // [14] raygen calls, [15] raygen lanes
     unsigned long long phase[16];
 #endif
+    int deferred[kDeferCap];  // pixel indices; NOT cleared between launches (the host clears up to here)
 };
 
 constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
@@ -537,10 +540,52 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
 // primary rays (measured on the teapots scene: 2.97 ms for 2.07 M rays, a quarter of k_pt_persistent's rate).  Here lanes
 // are refilled: a lane whose ray has ended writes its G-buffer record (batched: once 16 lanes wait) and takes the next
 // pixel.  Same centre ray, same walk, same record per pixel as k_gbuffer.
+// One pixel's G-buffer record (gBuffer.cu:28-67), from the primary ray's closest hit.
+RD_DEV void gbufStore(const DScene &s, const DCamera &cam, const DCamera &lastCam, const GBufPtrs &gb, int idx, const RaySlab &rs,
+                      int hitPrim, v2 hitBary) {
+    if (hitPrim != -1) {
+        Surface isec;
+        fetchSurface(s, hitPrim, hitBary, isec);
+        int matId = isec.matId;
+        if (loadMaterial(s.mats, isec.matId).type == Light) matId = -2;  // NullPrimitive - 1 (gBuffer.cu:33-37)
+        Material material = texturedMaterial(s, isec);                  // :44 (may perturb isec.norm)
+        store3(gb.albedo, idx, material.baseColor);
+        store3(gb.normal, idx, isec.norm);
+        gb.primId[idx] = matId;
+        gb.depth[idx] = length(rs.o - isec.pos);
+        v2 ndc = cameraRasterUV(lastCam, isec.pos);
+        int lx = (int)(float(lastCam.resx) * ndc.x), ly = (int)(float(lastCam.resy) * ndc.y);
+        gb.motion[idx] = (lx >= 0 && lx < gb.width && ly >= 0 && ly < gb.height) ? ly * cam.resx + lx : -1;
+    } else {
+        store3(gb.albedo, idx, hasEnvMap(s) ? envLookup(s, rs.d) : mk3(0.f));  // :61-66
+        store3(gb.normal, idx, mk3(0.f));
+        gb.primId[idx] = -1;
+        gb.depth[idx] = 1.f;
+        gb.motion[idx] = 0;
+    }
+}
+
+// The un-jittered centre ray of pixel (x, y) (gBuffer.cu:11-26).
+RD_DEV Ray gbufPrimaryRay(const DCamera &cam, int x, int y) {
+    float aspect = float(cam.resx) / float(cam.resy);
+    v2 pixelsize = {1.f / float(cam.resx), 1.f / float(cam.resy)};
+    v2 scr = mk2(float(x), float(y)) * pixelsize;
+    v2 ruv = scr + pixelsize * mk2(0.5f, 0.5f);
+    ruv = {1.f - ruv.x * 2.f, 1.f - ruv.y * 2.f};
+    v3 pLens = mk3(0.f);
+    v2 f = (ruv * mk2(aspect, 1.f)) * cam.tanFovY;
+    v3 pFocus = mk3(f.x, f.y, 1.f) * cam.focalDist;
+    v3 dir = pFocus - pLens;
+    Ray ray;
+    ray.o = cam.position + cam.right * pLens.x + cam.up * pLens.y;
+    ray.d = normalize(mul(m3{cam.right, cam.up, cam.view}, dir));
+    return ray;
+}
+
 #ifndef RD_GB_FINISH_MIN
 #define RD_GB_FINISH_MIN 16
 #endif
-template <bool COUNT>
+template <bool COUNT, bool DEFER>
 __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam, DCamera lastCam, PixelMap pm, GBufPtrs gb,
                                                            PersistCounters *pc) {
     const int lane = int(threadIdx.x) & 63;
@@ -565,6 +610,7 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
     float tmax = 0.f;
     int hitPrim = -1;
     v2 hitBary = mk2(0.f, 0.f);
+    const bool deferAll = DEFER && pc->deferCount <= kDeferCap;  // written by k_gbuffer_find_literal, earlier in the stream
 
     for (;;) {
         // ---------------- new pixels for idle lanes ----------------
@@ -593,27 +639,19 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
                     Pix px = mapPixel(pm, blk, (unsigned)(slotNext + (myRank - taken)));
                     if (px.valid && ok) {
                         pixIdx = px.index;
-                        // the un-jittered centre ray of gBuffer.cu:11-26
-                        float aspect = float(cam.resx) / float(cam.resy);
-                        v2 pixelsize = {1.f / float(cam.resx), 1.f / float(cam.resy)};
-                        v2 scr = mk2(float(px.x), float(px.y)) * pixelsize;
-                        v2 ruv = scr + pixelsize * mk2(0.5f, 0.5f);
-                        ruv = {1.f - ruv.x * 2.f, 1.f - ruv.y * 2.f};
-                        v3 pLens = mk3(0.f);
-                        v2 f = (ruv * mk2(aspect, 1.f)) * cam.tanFovY;
-                        v3 pFocus = mk3(f.x, f.y, 1.f) * cam.focalDist;
-                        v3 dir = pFocus - pLens;
-                        Ray ray;
-                        ray.o = cam.position + cam.right * pLens.x + cam.up * pLens.y;
-                        ray.d = normalize(mul(m3{cam.right, cam.up, cam.view}, dir));
+                        Ray ray = gbufPrimaryRay(cam, px.x, px.y);
                         rs = makeRaySlab(ray);
                         nodes = s.nodes[getMTBVHId(-ray.d)];
                         node = 0;
                         pending = -1;
                         hitPrim = -1;
                         tmax = 3.402823466e+38f;
-                        nClosest++;
-                        state = G_TRACE;
+                        if (DEFER && rs.cls != 0 && end != 0 && deferAll) {
+                            // a literal-class ray: k_gbuffer_literal has it (found by k_gbuffer_find_literal)
+                        } else {
+                            nClosest++;
+                            state = G_TRACE;
+                        }
                     }
                 }
                 slotNext += give;
@@ -697,34 +735,52 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
             const int nBusy = __popcll(__ballot(state != G_IDLE));
             if (doneM != 0ull && __popcll(doneM) * 64 >= nBusy * RD_GB_FINISH_MIN) {
                 if (state == G_DONE) {
-                    const int idx = pixIdx;
-                    if (hitPrim != -1) {
-                        nHits++;
-                        Surface isec;
-                        fetchSurface(s, hitPrim, hitBary, isec);
-                        int matId = isec.matId;
-                        if (loadMaterial(s.mats, isec.matId).type == Light) matId = -2;  // NullPrimitive - 1 (gBuffer.cu:33-37)
-                        Material material = texturedMaterial(s, isec);                  // :44 (may perturb isec.norm)
-                        store3(gb.albedo, idx, material.baseColor);
-                        store3(gb.normal, idx, isec.norm);
-                        gb.primId[idx] = matId;
-                        gb.depth[idx] = length(rs.o - isec.pos);
-                        v2 ndc = cameraRasterUV(lastCam, isec.pos);
-                        int lx = (int)(float(lastCam.resx) * ndc.x), ly = (int)(float(lastCam.resy) * ndc.y);
-                        gb.motion[idx] = (lx >= 0 && lx < gb.width && ly >= 0 && ly < gb.height) ? ly * cam.resx + lx : -1;
-                    } else {
-                        store3(gb.albedo, idx, hasEnvMap(s) ? envLookup(s, rs.d) : mk3(0.f));  // :61-66
-                        store3(gb.normal, idx, mk3(0.f));
-                        gb.primId[idx] = -1;
-                        gb.depth[idx] = 1.f;
-                        gb.motion[idx] = 0;
-                    }
+                    if (hitPrim != -1) nHits++;
+                    gbufStore(s, cam, lastCam, gb, pixIdx, rs, hitPrim, hitBary);
                     state = G_IDLE;
                 }
             }
         }
     }
     if (COUNT) flushCounters(s.counters, nClosest, 0u, nHits, ws);
+}
+
+// Literal-class primary rays are traced apart, each by a whole 1 024-thread workgroup (wg_trace.h), in a launch that runs
+// BESIDE k_gbuffer_persistent on a second stream: traced in place by one wave, one such ray takes 1.2 ms on the teapots scene,
+// twice the rest of the pass.  The ray's class depends on the camera and the pixel only, so a first tiny kernel lists them;
+// when there are more than kDeferCap (an axis-aligned camera makes a whole pixel row such rays) none is set aside — many
+// one-wave traces in parallel are the better use of the chip then.
+__global__ __launch_bounds__(256) void k_gbuffer_find_literal(DScene s, DCamera cam, PersistCounters *pc) {
+    const int idx = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= cam.resx * cam.resy || s.bvhSize == 0) return;
+    Ray ray = gbufPrimaryRay(cam, idx % cam.resx, idx / cam.resx);
+    if (makeRaySlab(ray).cls != 0) {
+        const int at = atomicAdd(&pc->deferCount, 1);
+        if (at < kDeferCap) pc->deferred[at] = idx;
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kWgTraceThreads) void k_gbuffer_literal(DScene s, DCamera cam, DCamera lastCam, GBufPtrs gb,
+                                                                      const PersistCounters *pc) {
+    __shared__ WgTraceShared sh;
+    const int n = pc->deferCount;
+    if (n > kDeferCap) return;  // k_gbuffer_persistent traces them all in place
+    for (int i = int(blockIdx.x); i < n; i += int(gridDim.x)) {
+        const int idx = pc->deferred[i];
+        Ray ray = gbufPrimaryRay(cam, idx % cam.resx, idx / cam.resx);
+        RaySlab rs = makeRaySlab(ray);
+        CoopTrace ct = wgTraceWhole<false>(s, s.nodes[getMTBVHId(-ray.d)], rs, 3.402823466e+38f, sh);
+        if (threadIdx.x == 0) {
+            gbufStore(s, cam, lastCam, gb, idx, rs, ct.hitPrim, ct.bary);
+            if (COUNT) {
+                atomicAdd(&s.counters->closestRays, 1ull);
+                atomicAdd(&s.counters->nodeVisits, (unsigned long long)ct.nodes);
+                atomicAdd(&s.counters->triTests, (unsigned long long)ct.tris);
+                if (ct.hitPrim != -1) atomicAdd(&s.counters->closestHits, 1ull);
+            }
+        }
+    }
 }
 
 }  // namespace rd

@@ -29,6 +29,8 @@ struct rdh_ctx {
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evStop = nullptr;
+    hipStream_t sideStream = nullptr;  // k_gbuffer_literal runs here, beside k_gbuffer_persistent
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     bool timed = false;
     std::string err;
 
@@ -261,6 +263,9 @@ int rdh_create(rdh_ctx **out, int device) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&c->dCounters, sizeof(Counters)) != hipSuccess ||
         hipMalloc((void **)&c->dPersist, sizeof(PersistCounters)) != hipSuccess) {
         delete c;
@@ -296,6 +301,9 @@ void rdh_destroy(rdh_ctx *c) {
     if (c->blockOrder) hipFree(c->blockOrder);
     if (c->evStart) hipEventDestroy(c->evStart);
     if (c->evStop) hipEventDestroy(c->evStop);
+    if (c->evFork) hipEventDestroy(c->evFork);
+    if (c->evJoin) hipEventDestroy(c->evJoin);
+    if (c->sideStream) hipStreamDestroy(c->sideStream);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -538,7 +546,7 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
             hipLaunchKernelGGL(k_persist_schedule, dim3(1), dim3(256), 0, c->stream, c->blockCost, c->blockEma, c->blockOrder, pm.numBlocks);
         else
             HIP_TRY(c, hipMemsetAsync(c->blockCost, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, sizeof(PersistCounters), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
         const int *order = useOrder ? c->blockOrder : nullptr;
         long pp = profBegin(c, flags);
         if (count)
@@ -612,18 +620,39 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
     // persistent launch with lane refill: as many single-wave workgroups as stay resident, never more than there is work
     if (c->gbufGrid == 0) {
         int perCU = 0, cus = 0;
-        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_gbuffer_persistent<false>, 64, 0));
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_gbuffer_persistent<false, true>), 64, 0));
         HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
         c->gbufGrid = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
     }
     unsigned groups = (((unsigned)(pm.numBlocks + 3) / 4 + 7u) / 8u) * 8u * 4u;
     unsigned grid = groups < c->gbufGrid ? groups : c->gbufGrid;
     timeBegin(c);
-    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, sizeof(PersistCounters), c->stream));
-    if (flags & RDH_PT_COUNT)
-        hipLaunchKernelGGL(k_gbuffer_persistent<true>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
+    // literal-class rays are listed first and traced on a second stream beside the rest, each by a whole workgroup
+    // (kernels_persist.h, k_gbuffer_literal): traced in place, ONE such ray (1.2 ms on the teapots scene) was the duration of
+    // the pass.  RDH_PT_NO_DEFER keeps them in the persistent kernel.
+    const bool defer = !(flags & RDH_PT_NO_DEFER);
+    const bool count = (flags & RDH_PT_COUNT) != 0;
+    if (defer) {
+        const unsigned pixels = (unsigned)(c->cam.resx * c->cam.resy);
+        hipLaunchKernelGGL(k_gbuffer_find_literal, dim3((pixels + 255u) / 256u), dim3(256), 0, c->stream, c->ds, c->cam, c->dPersist);
+        HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evFork, 0));
+        if (count)
+            hipLaunchKernelGGL(k_gbuffer_literal<true>, dim3(kDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, c->cam, last, p, c->dPersist);
+        else
+            hipLaunchKernelGGL(k_gbuffer_literal<false>, dim3(kDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, c->cam, last, p, c->dPersist);
+        HIP_TRY(c, hipEventRecord(c->evJoin, c->sideStream));
+    }
+    if (count && defer)
+        hipLaunchKernelGGL((k_gbuffer_persistent<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+    else if (count)
+        hipLaunchKernelGGL((k_gbuffer_persistent<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+    else if (defer)
+        hipLaunchKernelGGL((k_gbuffer_persistent<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
     else
-        hipLaunchKernelGGL(k_gbuffer_persistent<false>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+        hipLaunchKernelGGL((k_gbuffer_persistent<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+    if (defer) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evJoin, 0));
     return timeEnd(c, "renderGBuffer");
 }
 

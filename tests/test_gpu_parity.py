@@ -271,6 +271,64 @@ def test_gbuffer_kernels_bit_exact(gpu_ctx, kernel):
     assert (gb_ref.primId[0] >= 0).mean() > 0.3
 
 
+def _count_literal_primary_rays(cam):
+    """How many un-jittered centre rays of `cam` have a direction component below the box test's Eps (bvh.h:138-148)."""
+    W, H = int(cam["resolution"][0]), int(cam["resolution"][1])
+    x, y = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    ru = 1.0 - (x + 0.5) / W * 2.0
+    rv = 1.0 - (y + 0.5) / H * 2.0
+    t = float(cam["tanFovY"])
+    d = (ru * (W / H) * t)[..., None] * cam["right"].astype(np.float64) + (rv * t)[..., None] * cam["up"].astype(np.float64) \
+        + cam["view"].astype(np.float64)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    return int((np.abs(d) < 5e-7).any(axis=-1).sum())
+
+
+@pytest.mark.parametrize("size", [(151, 91), (301, 45)])
+@pytest.mark.parametrize("defer", [True, False])
+def test_gbuffer_literal_rays_bit_exact(gpu_ctx, defer, size):
+    """Primary rays with an axis-parallel direction component take the box test's special cases (bvh.h:138-148) and visit
+    a large part of the tree.  rdh_gbuffer_render lists them for k_gbuffer_literal, where a whole workgroup traces
+    each (wg_trace.h) — unless the frame has more than 256 of them (the second size) or RDH_PT_NO_DEFER is given: then one wave
+    traces each in place.  An axis-aligned camera with odd dimensions makes the whole centre row and column such rays; planes
+    and work counters equal the oracle's either way."""
+    from oracle import pyoracle
+    from radish_pt_amd import api, hostlib, scenes
+
+    sd = scenes.teapots(segments=12, bands=8, grid=2, emissive_grid=(4, 8))
+    gpu_ctx.set_partition(0, 1, 64)
+    gpu_ctx.upload_scene(sd)
+    o = _oracle(sd)
+    W, H = size
+    cams = [hostlib.make_camera(W, H, eye=(0.0, 1.0 + 0.5 * f, 9.0), rotation=(-90.0, 0.0, 0.0), fovy=19.0) for f in range(2)]
+    n_lit = _count_literal_primary_rays(cams[0])
+    assert (50 <= n_lit <= 256) if W == 151 else n_lit > 256
+    gb_ref = pyoracle.GBufferHost(W, H)
+    gb = api.GBuffer()
+    gb.create(W, H)
+    flags = api.RDH_PT_COUNT | (0 if defer else api.RDH_PT_NO_DEFER)
+    for cam in cams:
+        before = o.stats()
+        o.gbuffer_render(cam, gb_ref)
+        after = o.stats()
+        gpu_ctx.set_camera(cam)
+        gpu_ctx.counters_reset()
+        gpu_ctx.gbuffer_render(gb.c_struct(cam_fallback=cam), flags)
+        gpu_ctx.synchronize()
+        cur = gb.frameIdx
+        assert np.array_equal(gb.primId[cur].cpu().numpy(), gb_ref.primId[cur])
+        assert np.array_equal(gb.motion.cpu().numpy(), gb_ref.motion)
+        assert_bit_equal(gb.albedo.cpu().numpy(), gb_ref.albedo, "albedo")
+        assert_bit_equal(gb.normal[cur].cpu().numpy(), gb_ref.normal[cur], "normal")
+        assert_bit_equal(gb.depth[cur].cpu().numpy(), gb_ref.depth[cur], "depth")
+        ct = gpu_ctx.counters()
+        for k in ("closestRays", "nodeVisits", "triTests", "closestHits"):
+            assert ct[k] == after[k] - before[k], k
+        gb_ref.update(cam)
+        gb.update(cam)
+    assert (gb_ref.primId[0] >= 0).mean() > 0.2
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Full-size properties (oracle too slow): implementations must agree with each other bit for bit at 1080p
 # ---------------------------------------------------------------------------------------------------------------------
