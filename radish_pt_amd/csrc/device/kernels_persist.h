@@ -55,17 +55,21 @@ constexpr int PS_IDLE = 0, PS_TRACE = 1, PS_SHADE = 2;
 // order of that figure (frames of an animation are coherent; the first frame uses plain order).  Pure scheduling:
 // which lane renders a pixel, and when, cannot change its value.
 constexpr int kCostBuckets = 64;
-// 256 threads, <= 64 VGPRs: as soon as one persistent wave of the previous frame has left a SIMD there is room for it, so
-// with two frames in flight the next frame's schedule does not queue behind the whole tail of the current frame.
+// One workgroup of 1 024 threads (a counting sort of ~32 000 blocks into 64 buckets).  The LDS counters are bumped once per
+// wave and bucket, not once per block: neighbouring blocks cost about the same, so a wave's 64 blocks fall into a handful of
+// buckets, and 64 lanes adding to ONE LDS word serialise (the first version did that from 256 threads: 104 us per frame, 3 %
+// of the Cornell frame, on the stream between two persistent launches; this one: see profiles/).
 // `ema`: running estimate of each block's cost over the frames so far (the per-launch figure is ONE sample of the longest of
 // 64 random paths — noisy; blocks differ systematically by what they look at).  ema' = (RD_EMA_KEEP * ema + cost) / (RD_EMA_KEEP + 1).
 #ifndef RD_EMA_KEEP
 #define RD_EMA_KEEP 7
 #endif
-__global__ __launch_bounds__(256) void k_persist_schedule(unsigned *__restrict__ cost, unsigned *__restrict__ ema,
-                                                          int *__restrict__ order, int n) {
+constexpr int kScheduleThreads = 1024;
+__global__ __launch_bounds__(kScheduleThreads) void k_persist_schedule(unsigned *__restrict__ cost, unsigned *__restrict__ ema,
+                                                                       int *__restrict__ order, int n) {
     __shared__ int hist[kCostBuckets], base[kCostBuckets];
     const int t = int(threadIdx.x);
+    const int lane = t & 63;
     if (t < kCostBuckets) hist[t] = 0;
     __syncthreads();
     auto bucketOf = [](unsigned c) {  // quarter-octave buckets, descending: bucket 0 = most expensive
@@ -78,26 +82,51 @@ __global__ __launch_bounds__(256) void k_persist_schedule(unsigned *__restrict__
         if (b > kCostBuckets - 1) b = kCostBuckets - 1;
         return kCostBuckets - 1 - b;
     };
-    for (int i = t; i < n; i += 256) {
-        const unsigned e = ema[i] == 0u ? cost[i] : (RD_EMA_KEEP * ema[i] + cost[i] + RD_EMA_KEEP / 2) / (RD_EMA_KEEP + 1);
-        ema[i] = e;
-        atomicAdd(&hist[bucketOf(e)], 1);
-    }
-    __syncthreads();
-    if (t == 0) {
-        int acc = 0;
-        for (int b = 0; b < kCostBuckets; b++) {
-            base[b] = acc;
-            acc += hist[b];
+    // add `1` per lane of the wave to counter[bucket] with one atomic per distinct bucket; returns the lane's slot
+    auto waveAdd = [&](int *counter, int bucket, bool valid) {
+        int slot = 0;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int L = __ffsll((long long)todo) - 1;
+            const int b0 = __shfl(bucket, L, 64);
+            const unsigned long long same = __ballot(valid && bucket == b0);
+            int first = 0;
+            if (lane == L) first = atomicAdd(&counter[b0], __popcll(same));
+            first = __shfl(first, L, 64);
+            if (valid && bucket == b0) slot = first + __popcll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
         }
+        return slot;
+    };
+    for (int i0 = 0; i0 < n; i0 += kScheduleThreads) {
+        const int i = i0 + t;
+        const bool valid = i < n;
+        unsigned e = 0u;
+        if (valid) {
+            const unsigned old = ema[i], c = cost[i];
+            e = old == 0u ? c : (RD_EMA_KEEP * old + c + RD_EMA_KEEP / 2) / (RD_EMA_KEEP + 1);
+            ema[i] = e;
+            cost[i] = 0u;
+        }
+        waveAdd(hist, bucketOf(e), valid);
     }
     __syncthreads();
-    for (int i = t; i < n; i += 256) {  // order inside a bucket is arrival order: ties are equally expensive
-        int pos = atomicAdd(&base[bucketOf(ema[i])], 1);
-        order[pos] = i;
+    if (t < 64) {  // exclusive prefix sum of the 64 bucket sizes
+        int v = hist[t], incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (t >= d) incl += up;
+        }
+        base[t] = incl - v;
     }
     __syncthreads();
-    for (int i = t; i < n; i += 256) cost[i] = 0u;
+    for (int i0 = 0; i0 < n; i0 += kScheduleThreads) {  // order inside a bucket: ties are equally expensive
+        const int i = i0 + t;
+        const bool valid = i < n;
+        const int b = valid ? bucketOf(ema[i]) : 0;
+        const int pos = waveAdd(base, b, valid);
+        if (valid) order[pos] = i;
+    }
 }
 
 #ifndef RD_PERSIST_WAVES

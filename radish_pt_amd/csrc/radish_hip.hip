@@ -543,7 +543,7 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         timeBegin(c);
         const bool useOrder = c->orderValid && !(flags & RDH_PT_NO_SCHEDULE);
         if (useOrder)
-            hipLaunchKernelGGL(k_persist_schedule, dim3(1), dim3(256), 0, c->stream, c->blockCost, c->blockEma, c->blockOrder, pm.numBlocks);
+            hipLaunchKernelGGL(k_persist_schedule, dim3(1), dim3(kScheduleThreads), 0, c->stream, c->blockCost, c->blockEma, c->blockOrder, pm.numBlocks);
         else
             HIP_TRY(c, hipMemsetAsync(c->blockCost, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
