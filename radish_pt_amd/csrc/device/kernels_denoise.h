@@ -60,6 +60,7 @@ RD_DEV float pow_det(float x, float y) {
 
 struct DenoiseGB {  // the planes of GBuffer the denoisers read (gBuffer.h:29-57), current / last already selected
     const float *albedo, *normal, *lastNormal, *depth;
+    const float *position;  // k_position_plane's output (filters only): Camera::getPosition of every pixel, computed once
     const int *motion, *primId, *lastPrimId;
     int width, height;
 };
@@ -95,6 +96,16 @@ RD_DEV bool denoisePixel(int width, int height, int &x, int &y) {
     return x < width && y < height;
 }
 
+// The filters need Camera::getPosition(x, y, depth) of the pixel and of each of its 25 taps (denoiser.cu:47-48, :127-128):
+// ~110 instructions with an IEEE square root and three divisions, 40 % of a tap.  It depends on the tap's pixel only, so it
+// is computed once per pixel into a plane (same function, same bits) and the taps read 12 B instead.
+__global__ __launch_bounds__(256) void k_position_plane(float *__restrict__ position, const float *__restrict__ depth, DCamera cam) {
+    int x, y;
+    if (!denoisePixel(cam.resx, cam.resy, x, y)) return;
+    const int idx = x + y * cam.resx;
+    store3(position, idx, cameraGetPosition(cam, x, y, depth[idx]));
+}
+
 __global__ __launch_bounds__(256) void k_eaw_filter(float *__restrict__ colorOut, const float *__restrict__ colorIn, DenoiseGB gb,
                                                     float sigDepth, float sigNormal, float sigLuminance, DCamera cam, int level) {
     int x, y;
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(256) void k_eaw_filter(float *__restrict__ colorOut
     }
     const v3 colorP = load3(colorIn, idxP);
     const v3 normalP = load3(gb.normal, idxP);
-    const v3 posP = cameraGetPosition(cam, x, y, gb.depth[idxP]);
+    const v3 posP = load3(gb.position, idxP);
     v3 sum = mk3(0.f);
     float weightSum = 0.f;
     for (int i = -2; i <= 2; i++)
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(256) void k_eaw_filter(float *__restrict__ colorOut
             const int idxQ = qx + qy * cam.resx;
             if (gb.primId[idxQ] != primIdP) continue;
             const v3 normalQ = load3(gb.normal, idxQ);
-            const v3 posQ = cameraGetPosition(cam, qx, qy, gb.depth[idxQ]);
+            const v3 posQ = load3(gb.position, idxQ);
             const v3 colorQ = load3(colorIn, idxQ);
             const v3 dc = colorP - colorQ, dn = normalP - normalQ, dp = posP - posQ;
             const float wColor = gmin(1.f, exp_det(-dot(dc, dc) / sigLuminance));
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) void k_svgf_filter(float *__restrict__ colorOu
     }
     const v3 colorP = load3(colorIn, idxP);
     const v3 normalP = load3(gb.normal, idxP);
-    const v3 posP = cameraGetPosition(cam, x, y, gb.depth[idxP]);
+    const v3 posP = load3(gb.position, idxP);
     v3 colorSum = mk3(0.f);
     float varianceSum = 0.f, weightSum = 0.f, weight2Sum = 0.f;
     for (int i = -2; i <= 2; i++)
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256) void k_svgf_filter(float *__restrict__ colorOu
             if (qx >= cam.resx || qy >= cam.resy || qx < 0 || qy < 0) continue;
             const int idxQ = qx + qy * cam.resx;
             const v3 normalQ = load3(gb.normal, idxQ);
-            const v3 posQ = cameraGetPosition(cam, qx, qy, gb.depth[idxQ]);
+            const v3 posQ = load3(gb.position, idxQ);
             const float varQ = varianceIn[idxQ];
             const v3 colorQ = load3(colorIn, idxQ);
             const v3 dp = posP - posQ;

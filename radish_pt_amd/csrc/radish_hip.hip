@@ -42,6 +42,8 @@ struct rdh_ctx {
     PersistCounters *dPersist = nullptr;
     unsigned persistGrid = 0;
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
+    float *posPlane = nullptr;  // denoisers: Camera::getPosition of every pixel (k_position_plane)
+    long long posPlanePixels = 0;
     unsigned *blockCost = nullptr;  // per-8x8-block cost of the previous persistent launch (k_persist_schedule)
     unsigned *blockEma = nullptr;   // running mean of it over the launches so far
     int *blockOrder = nullptr;
@@ -296,6 +298,7 @@ void rdh_destroy(rdh_ctx *c) {
     for (hipEvent_t e : c->profEvents) hipEventDestroy(e);
     if (c->dCounters) hipFree(c->dCounters);
     if (c->dPersist) hipFree(c->dPersist);
+    if (c->posPlane) hipFree(c->posPlane);
     if (c->blockCost) hipFree(c->blockCost);
     if (c->blockEma) hipFree(c->blockEma);
     if (c->blockOrder) hipFree(c->blockOrder);
@@ -884,11 +887,29 @@ int denoiseGB(rdh_ctx *c, const rdh_gbuffer *gb, DenoiseGB &d, const char *what)
     for (int k = 0; k < 2; k++)
         if (!gb->normal[k] || !gb->depth[k] || !gb->primId[k]) return fail(c, RDH_ERR_ARGS, "%s: null G-buffer plane", what);
     const int f = gb->frameIdx;
-    d = DenoiseGB{gb->albedo, gb->normal[f], gb->normal[f ^ 1], gb->depth[f], gb->motion, gb->primId[f], gb->primId[f ^ 1],
+    d = DenoiseGB{gb->albedo, gb->normal[f], gb->normal[f ^ 1], gb->depth[f], nullptr, gb->motion, gb->primId[f], gb->primId[f ^ 1],
                   gb->width, gb->height};
     return RDH_OK;
 }
 dim3 denoiseGrid(int w, int h) { return dim3((unsigned)((w + 31) / 32), (unsigned)((h + 7) / 8)); }
+// world-space position of every pixel for the filter launched next (recomputed per launch: the depth plane behind the
+// pointer changes from frame to frame, and 10 us buy 40 % of the filter's arithmetic)
+int denoisePositions(rdh_ctx *c, DenoiseGB &d, const DCamera &cam) {
+    const long long n = (long long)cam.resx * cam.resy;
+    if (n > c->posPlanePixels) {
+        if (c->posPlane) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            hipFree(c->posPlane);
+            c->posPlane = nullptr;
+            c->posPlanePixels = 0;
+        }
+        HIP_TRY(c, hipMalloc((void **)&c->posPlane, sizeof(float) * 3 * (size_t)n));
+        c->posPlanePixels = n;
+    }
+    hipLaunchKernelGGL(k_position_plane, denoiseGrid(cam.resx, cam.resy), dim3(256), 0, c->stream, c->posPlane, d.depth, cam);
+    d.position = c->posPlane;
+    return RDH_OK;
+}
 }  // namespace
 }  // extern "C++"
 
@@ -901,6 +922,8 @@ int rdh_denoise_eaw(rdh_ctx *c, float *d_colorOut, const float *d_colorIn, const
     DCamera cam = toDeviceCamera(camera196);
     if (cam.resx != gb->width || cam.resy != gb->height) return fail(c, RDH_ERR_ARGS, "rdh_denoise_eaw: camera / G-buffer size mismatch");
     HIP_TRY(c, hipSetDevice(c->device));
+    rc = denoisePositions(c, d, cam);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_eaw_filter, denoiseGrid(cam.resx, cam.resy), dim3(256), 0, c->stream, d_colorOut, d_colorIn, d, sigDepth,
                        sigNormal, sigLumin, cam, level);
     HIP_TRY(c, hipGetLastError());
@@ -918,6 +941,8 @@ int rdh_denoise_svgf(rdh_ctx *c, float *d_colorOut, const float *d_colorIn, floa
     DCamera cam = toDeviceCamera(camera196);
     if (cam.resx != gb->width || cam.resy != gb->height) return fail(c, RDH_ERR_ARGS, "rdh_denoise_svgf: camera / G-buffer size mismatch");
     HIP_TRY(c, hipSetDevice(c->device));
+    rc = denoisePositions(c, d, cam);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_svgf_filter, denoiseGrid(cam.resx, cam.resy), dim3(256), 0, c->stream, d_colorOut, d_colorIn, d_varianceOut,
                        d_varianceIn, d_filteredVar, d, sigDepth, sigNormal, sigLumin, cam, level);
     HIP_TRY(c, hipGetLastError());
