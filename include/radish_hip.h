@@ -203,7 +203,10 @@ int rdh_denoise_filter_variance(rdh_ctx *ctx, float *d_varianceOut, const float 
 int rdh_restir_read(rdh_ctx *ctx, int which, void *hostOut);
 
 /* ---- traversal entry points (tests / roofline bench) ------------------------------------------------ */
-/* d_rays: {origin.xyz, direction.xyz}[n].  DevScene::intersect (src/scene.h:262-301) per ray. */
+/* d_rays: {origin.xyz, direction.xyz}[n].  DevScene::intersect (src/scene.h:262-301) per ray.
+   flags: RDH_PT_COUNT; RDH_PT_PERSISTENT selects the walk-only lane-refill kernel (device/kernels_walk.h: a lane whose ray
+   has ended takes the next ray of the batch; 1.6x the one-lane-per-ray kernel's rate, same records and counters) — for both
+   entries. */
 int rdh_trace_closest(rdh_ctx *ctx, const float *d_rays, int64_t n, rdh_hit *d_hits, uint32_t flags);
 /* d_segments: {x.xyz, y.xyz}[n] -> d_occluded[n] in {0,1}.  DevScene::testOcclusion (src/scene.h:303-334). */
 int rdh_trace_occluded(rdh_ctx *ctx, const float *d_segments, int64_t n, int32_t *d_occluded, uint32_t flags);

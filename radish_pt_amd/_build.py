@@ -14,7 +14,7 @@ HOST_SOURCES = [os.path.join(CSRC, "host", "scene_build.cpp"), os.path.join(CSRC
 HIP_SOURCES = [os.path.join(CSRC, "radish_hip.hip")]
 HIP_DEPS = [
     os.path.join(CSRC, "device", f)
-    for f in ("rmath.h", "layouts.h", "traverse.h", "bsdf.h", "lights.h", "kernels_pt.h", "kernels_restir.h", "kernels_wave.h", "kernels_persist.h", "wg_trace.h", "kernels_display.h", "kernels_denoise.h")
+    for f in ("rmath.h", "layouts.h", "traverse.h", "bsdf.h", "lights.h", "kernels_pt.h", "kernels_restir.h", "kernels_wave.h", "kernels_persist.h", "kernels_walk.h", "wg_trace.h", "kernels_display.h", "kernels_denoise.h")
 ] + [os.path.join(ROOT, "include", "radish_hip.h")]
 
 # -ffp-contract=off: the HIP path must execute the same IEEE-754 operation sequence as the CPU checker

@@ -298,10 +298,10 @@ class Context:
         self.check(lib().rdh_restir_read(self.h, which, out.ctypes.data))
         return out
 
-    def trace_closest(self, rays, hits, flags=0):
+    def trace_closest(self, rays, hits, flags=RDH_PT_PERSISTENT):  # flags without RDH_PT_PERSISTENT: one lane per ray
         self.check(lib().rdh_trace_closest(self.h, rays.data_ptr(), rays.numel() // 6, hits.data_ptr(), flags))
 
-    def trace_occluded(self, segments, out, flags=0):
+    def trace_occluded(self, segments, out, flags=RDH_PT_PERSISTENT):
         self.check(lib().rdh_trace_occluded(self.h, segments.data_ptr(), segments.numel() // 6, out.data_ptr(), flags))
 
     def counters_reset(self):

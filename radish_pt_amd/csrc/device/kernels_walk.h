@@ -1,0 +1,198 @@
+// radish_pt_amd/csrc/device/kernels_walk.h — a persistent WALK-ONLY kernel over a ray batch: box steps, leaf tests, retire, and
+// nothing else in its register allocation.
+//
+// k_trace_closest / k_trace_occluded (kernels_pt.h) give every ray a lane for the whole launch, so each wave waits for its
+// longest ray.  Here a lane whose ray has ended writes its record and takes the next ray of the batch (the lane-refill
+// structure of k_gbuffer_persistent, without a surface fetch).  DevScene::intersect (scene.h:262-301) /
+// DevScene::testOcclusion (:303-334) per lane, exactly as walkRay (traverse.h) performs them: same decisions, same counters.
+// Rays are handed out in chunks of 64 (the first chunk of a wave is its index, further ones come from an atomic counter).
+#pragma once
+#include "kernels_persist.h"
+
+namespace rd {
+
+#ifndef RD_WALK_REFILL_MIN
+#define RD_WALK_REFILL_MIN 16  // refill once this many lanes are idle
+#endif
+#ifndef RD_WALK_FINISH_MIN
+#define RD_WALK_FINISH_MIN 8  // retire once done lanes * 64 >= busy lanes * this
+#endif
+
+template <bool COUNT, bool ANY>
+__global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,
+                                                        int *__restrict__ occluded, PersistCounters *pc) {
+    const int lane = int(threadIdx.x) & 63;
+    const int end = s.bvhSize;
+    const long long chunks = (n + 63) / 64;
+    WalkStats ws{0, 0};
+    unsigned nRays = 0, nHits = 0;
+    long long curChunk = (long long)blockIdx.x;
+    int slotNext = 0;
+    const int gridWavesN = int(gridDim.x);
+    bool exhausted = curChunk >= chunks;
+
+    constexpr int W_IDLE = 0, W_TRACE = 1, W_DONE = 2;
+    int state = W_IDLE;
+    long long rayIdx = 0;
+    RaySlab rs;
+    rs.o = rs.d = rs.inv = mk3(0.f);
+    rs.cls = 0;
+    const NodeRec *nodes = s.nodes[0];
+    int node = end, pending = -1;
+    float tmax = 0.f;
+    int hitPrim = -1;
+    v2 hitBary = mk2(0.f, 0.f);
+    bool found = false;
+
+    for (;;) {
+        // ---------------- new rays for idle lanes ----------------
+        const unsigned long long idleM = __ballot(state == W_IDLE);
+        const int nIdle = __popcll(idleM);
+        if (!exhausted && nIdle >= RD_WALK_REFILL_MIN) {
+            const int myRank = __popcll(idleM & laneMaskLt());
+            int taken = 0;
+            while (taken < nIdle && !exhausted) {
+                if (slotNext == 64) {
+                    int b = 0;
+                    if (lane == 0) b = atomicAdd(&pc->blockHead, 1);
+                    curChunk = (long long)__shfl(b, 0, 64) + gridWavesN;
+                    slotNext = 0;
+                    if (curChunk >= chunks) {
+                        exhausted = true;
+                        break;
+                    }
+                }
+                const int avail = 64 - slotNext;
+                const int give = (nIdle - taken) < avail ? (nIdle - taken) : avail;
+                if (state == W_IDLE && myRank >= taken && myRank < taken + give) {
+                    const long long i = curChunk * 64 + slotNext + (myRank - taken);
+                    if (i < n) {
+                        rayIdx = i;
+                        const v3 a = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+                        const v3 b = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+                        Ray ray;
+                        if (ANY) {  // testOcclusion(a, b) (scene.h:303-315)
+                            v3 dir = b - a;
+                            float dist = length(dir);
+                            dir = dir / dist;
+                            ray = makeOffsetedRay(a, dir);
+                            tmax = dist - 1e-4f;
+                        } else {
+                            ray = Ray{a, b};
+                            tmax = 3.402823466e+38f;
+                        }
+                        rs = makeRaySlab(ray);
+                        nodes = s.nodes[getMTBVHId(-ray.d)];
+                        node = 0;
+                        pending = -1;
+                        hitPrim = -1;
+                        hitBary = mk2(0.f, 0.f);
+                        found = false;
+                        nRays++;
+                        state = W_TRACE;
+                    }
+                }
+                slotNext += give;
+                taken += give;
+            }
+        }
+        if (__ballot(state != W_IDLE) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---------------- literal-class rays: traced whole by the whole wave ----------------
+        {
+            unsigned long long lit = __ballot(state == W_TRACE && rs.cls != 0 && node == 0 && pending < 0 && end != 0);
+            while (lit) {
+                const int L = __ffsll((long long)lit) - 1;
+                lit &= lit - 1ull;
+                CoopTrace ct = coopTraceWhole<ANY>(s, readlanePtr(nodes, L), readlaneRay(rs, L), readlaneF(tmax, L));
+                if (lane == L) {
+                    hitPrim = ct.hitPrim;
+                    hitBary = ct.bary;
+                    tmax = ct.tmax;
+                    found = ct.found;
+                    node = end;
+                    if (COUNT) {
+                        ws.nodes += ct.nodes;
+                        ws.tris += ct.tris;
+                    }
+                }
+            }
+        }
+        // ---------------- box steps ----------------
+        {
+            bool walking = state == W_TRACE && pending < 0 && node != end;
+            const int nStart = __popcll(__ballot(walking));
+            if (nStart == 1) {
+                const int L = __ffsll((long long)__ballot(walking)) - 1;
+                CoopResult cr = coopWalk(readlanePtr(nodes, L), readlaneI(node, L), end, readlaneRay(rs, L), readlaneF(tmax, L),
+                                         RD_COOP_WINDOWS);
+                if (lane == L) {
+                    node = cr.node;
+                    pending = cr.pending;
+                    if (COUNT) ws.nodes += cr.visited;
+                }
+            } else if (nStart > 0) {
+                const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
+                do {
+                    if (walking) {
+                        float4 lo = nodes[node].lo_prim;
+                        float4 hi = nodes[node].hi_next;
+                        float boundDist;
+                        if (COUNT) ws.nodes++;
+                        bool boundHit = aabbFast(lo, hi, rs, boundDist);
+                        if (boundHit && boundDist < tmax) {
+                            pending = __float_as_int(lo.w);
+                            node++;
+                        } else {
+                            node = __float_as_int(hi.w);
+                        }
+                        walking = pending < 0 && node != end;
+                    }
+                } while (__popcll(__ballot(walking)) >= (minWalk > 1 ? minWalk : 1));
+            }
+        }
+        // ---------------- leaf tests ----------------
+        if (state == W_TRACE && pending >= 0) {
+            TriVerts tv = loadTri(s.tris, pending);
+            float dist;
+            v2 bary;
+            if (COUNT) ws.tris++;
+            bool hit = intersectTriangle(rs, tv.a, tv.b, tv.c, bary, dist);
+            if (hit && dist < tmax) {
+                if (ANY) {
+                    found = true;
+                    node = end;
+                } else {
+                    hitPrim = pending;
+                    tmax = dist;
+                    hitBary = bary;
+                }
+            }
+            pending = -1;
+        }
+        if (state == W_TRACE && pending < 0 && node == end) state = W_DONE;
+        // ---------------- records of finished rays ----------------
+        {
+            const unsigned long long doneM = __ballot(state == W_DONE);
+            const int nBusy = __popcll(__ballot(state != W_IDLE));
+            if (doneM != 0ull && __popcll(doneM) * 64 >= nBusy * RD_WALK_FINISH_MIN) {
+                if (state == W_DONE) {
+                    if (ANY) {
+                        occluded[rayIdx] = found ? 1 : 0;
+                    } else {
+                        const bool hit = hitPrim != -1;
+                        if (hit) nHits++;
+                        hits[rayIdx] = make_int4(hitPrim, __float_as_int(hit ? hitBary.x : 0.f), __float_as_int(hit ? hitBary.y : 0.f),
+                                                 __float_as_int(hit ? tmax : 3.402823466e+38f));
+                    }
+                    state = W_IDLE;
+                }
+            }
+        }
+    }
+    if (COUNT) flushCounters(s.counters, ANY ? 0u : nRays, ANY ? nRays : 0u, nHits, ws);
+}
+
+}  // namespace rd

@@ -19,6 +19,7 @@
 #include "device/kernels_restir.h"
 #include "device/kernels_wave.h"
 #include "device/kernels_persist.h"
+#include "device/kernels_walk.h"
 #include "device/kernels_display.h"
 #include "device/kernels_denoise.h"
 
@@ -42,6 +43,7 @@ struct rdh_ctx {
     PersistCounters *dPersist = nullptr;
     unsigned persistGrid = 0;
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
+    unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
     float *posPlane = nullptr;  // denoisers: Camera::getPosition of every pixel (k_position_plane)
     long long posPlanePixels = 0;
     unsigned *blockCost = nullptr;  // per-8x8-block cost of the previous persistent launch (k_persist_schedule)
@@ -784,12 +786,41 @@ int rdh_restir_read(rdh_ctx *c, int which, void *hostOut) {
     return RDH_OK;
 }
 
+// RDH_PT_PERSISTENT on the ray-batch entries: the walk-only lane-refill kernel (device/kernels_walk.h); d_hits xor d_occ
+extern "C++" {
+static int walkPersistent(rdh_ctx *c, const float *d_rays, int64_t n, int4 *d_hits, int *d_occ, uint32_t flags, const char *what) {
+    const int any = d_occ ? 1 : 0;
+    if (c->walkGrid[any] == 0) {
+        int perCU = 0, cus = 0;
+        if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, true>), 64, 0));
+        else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, false>), 64, 0));
+        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->walkGrid[any] = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
+    }
+    const unsigned long long chunks = (unsigned long long)((n + 63) / 64);
+    const unsigned grid = chunks < c->walkGrid[any] ? (unsigned)chunks : c->walkGrid[any];
+    timeBegin(c);
+    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
+    const bool count = (flags & RDH_PT_COUNT) != 0;
+    if (any && count)
+        hipLaunchKernelGGL((k_walk_persistent<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ, c->dPersist);
+    else if (any)
+        hipLaunchKernelGGL((k_walk_persistent<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ, c->dPersist);
+    else if (count)
+        hipLaunchKernelGGL((k_walk_persistent<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ, c->dPersist);
+    else
+        hipLaunchKernelGGL((k_walk_persistent<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ, c->dPersist);
+    return timeEnd(c, what);
+}
+}
+
 int rdh_trace_closest(rdh_ctx *c, const float *d_rays, int64_t n, rdh_hit *d_hits, uint32_t flags) {
     if (!c) return RDH_ERR_ARGS;
     if (!c->haveScene) return fail(c, RDH_ERR_NO_SCENE, "no scene uploaded");
     if (n < 0 || (n > 0 && (!d_rays || !d_hits))) return fail(c, RDH_ERR_ARGS, "rdh_trace_closest: bad arguments");
     if (n == 0) return RDH_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (flags & RDH_PT_PERSISTENT) return walkPersistent(c, d_rays, n, (int4 *)d_hits, nullptr, flags, "trace_closest (persistent)");
     unsigned grid = (unsigned)((n + 255) / 256);
     timeBegin(c);
     if (flags & RDH_PT_COUNT)
@@ -805,6 +836,7 @@ int rdh_trace_occluded(rdh_ctx *c, const float *d_seg, int64_t n, int32_t *d_occ
     if (n < 0 || (n > 0 && (!d_seg || !d_occ))) return fail(c, RDH_ERR_ARGS, "rdh_trace_occluded: bad arguments");
     if (n == 0) return RDH_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (flags & RDH_PT_PERSISTENT) return walkPersistent(c, d_seg, n, nullptr, d_occ, flags, "trace_occluded (persistent)");
     unsigned grid = (unsigned)((n + 255) / 256);
     timeBegin(c);
     if (flags & RDH_PT_COUNT)

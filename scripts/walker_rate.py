@@ -19,10 +19,11 @@ for name in ("cornell", "teapots"):
     ctx = api.Context(0); ctx.upload_scene(sd)
     ctx.counters_reset(); ctx.trace_closest(rays, hits, api.RDH_PT_COUNT); ctx.synchronize()
     c = ctx.counters()
-    ts = []
-    for r in range(5):
-        torch.cuda.synchronize(); t0 = time.perf_counter(); ctx.trace_closest(rays, hits); ctx.synchronize(); ts.append(time.perf_counter() - t0)
-    t = min(ts)
-    print(f"{name}: {N} rays, {c['nodeVisits'] / N:.1f} steps per ray, {t * 1e3:.2f} ms -> {c['nodeVisits'] / t / 1e9:.0f} G box steps/s, "
-          f"{N / t / 1e6:.0f} Mrays/s, algorithmic {(40 * N + 32 * c['nodeVisits'] + 36 * c['triTests'] + 64 * c['closestHits']) / t / 1e9:.0f} GB/s")
+    for flags, kname in ((0, "one lane per ray"), (api.RDH_PT_PERSISTENT, "lane refill (k_walk_persistent)")):
+        ts = []
+        for r in range(5):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); ctx.trace_closest(rays, hits, flags); ctx.synchronize(); ts.append(time.perf_counter() - t0)
+        t = min(ts)
+        print(f"{name} [{kname}]: {N} rays, {c['nodeVisits'] / N:.1f} steps per ray, {t * 1e3:.2f} ms -> {c['nodeVisits'] / t / 1e9:.0f} G box steps/s, "
+              f"{N / t / 1e6:.0f} Mrays/s, algorithmic {(40 * N + 32 * c['nodeVisits'] + 36 * c['triTests'] + 64 * c['closestHits']) / t / 1e9:.0f} GB/s", flush=True)
     ctx.close()

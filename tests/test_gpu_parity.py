@@ -49,7 +49,8 @@ def cornell_gpu(gpu_ctx, cornell_small):
 # ---------------------------------------------------------------------------------------------------------------------
 # traversal
 # ---------------------------------------------------------------------------------------------------------------------
-def test_trace_closest_bit_exact(cornell_gpu, cornell_small):
+@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent"])
+def test_trace_closest_bit_exact(cornell_gpu, cornell_small, kernel):
     from radish_pt_amd import api, layouts as L
 
     torch = _torch()
@@ -59,7 +60,7 @@ def test_trace_closest_bit_exact(cornell_gpu, cornell_small):
     d_rays = _dev(rays)
     d_hits = torch.zeros(len(rays), 4, dtype=torch.int32, device="cuda")
     cornell_gpu.counters_reset()
-    cornell_gpu.trace_closest(d_rays, d_hits, api.RDH_PT_COUNT)
+    cornell_gpu.trace_closest(d_rays, d_hits, api.RDH_PT_COUNT | (api.RDH_PT_PERSISTENT if kernel == "persistent" else 0))
     got = d_hits.cpu().numpy().view(L.HIT_DTYPE).reshape(-1)
     assert np.array_equal(got["primId"], ref["primId"])
     for f in ("u", "v", "t"):
@@ -73,7 +74,8 @@ def test_trace_closest_bit_exact(cornell_gpu, cornell_small):
     assert ct["closestHits"] == st["closestHits"]
 
 
-def test_trace_occluded_exact(cornell_gpu, cornell_small):
+@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent"])
+def test_trace_occluded_exact(cornell_gpu, cornell_small, kernel):
     from radish_pt_amd import api
 
     torch = _torch()
@@ -82,7 +84,7 @@ def test_trace_occluded_exact(cornell_gpu, cornell_small):
     ref = o.trace_occluded(seg)
     d_out = torch.full((len(seg),), -1, dtype=torch.int32, device="cuda")
     cornell_gpu.counters_reset()
-    cornell_gpu.trace_occluded(_dev(seg), d_out, api.RDH_PT_COUNT)
+    cornell_gpu.trace_occluded(_dev(seg), d_out, api.RDH_PT_COUNT | (api.RDH_PT_PERSISTENT if kernel == "persistent" else 0))
     assert np.array_equal(d_out.cpu().numpy(), ref)
     assert 0.05 < ref.mean() < 0.95
     st, ct = o.stats(), cornell_gpu.counters()
@@ -94,9 +96,18 @@ def test_trace_empty_and_ragged(cornell_gpu, cornell_small):
     torch = _torch()
     cornell_gpu.trace_closest(torch.zeros(0, 6, device="cuda"), torch.zeros(0, 4, dtype=torch.int32, device="cuda"))
     rays = random_rays(257, seed=3)  # not a multiple of the 256-lane workgroup
-    d_hits = torch.full((257, 4), 7, dtype=torch.int32, device="cuda")
-    cornell_gpu.trace_closest(_dev(rays), d_hits)
     ref = _oracle(cornell_small).trace_closest(rays)
+    from radish_pt_amd import api
+    for flags in (0, api.RDH_PT_PERSISTENT):
+        d_hits = torch.full((257, 4), 7, dtype=torch.int32, device="cuda")
+        cornell_gpu.trace_closest(_dev(rays), d_hits, flags)
+        assert np.array_equal(d_hits.cpu().numpy()[:, 0], ref["primId"])
+    # axis-parallel directions (the box test's special cases, bvh.h:138-148) through the lane-refill walker's whole-wave trace
+    rays[::5, 3:] = np.array([0.0, 0.0, -1.0], np.float32)
+    rays[1::7, 3:] = np.array([1.0, 0.0, 0.0], np.float32)
+    ref = _oracle(cornell_small).trace_closest(rays)
+    d_hits = torch.full((257, 4), 7, dtype=torch.int32, device="cuda")
+    cornell_gpu.trace_closest(_dev(rays), d_hits, api.RDH_PT_PERSISTENT)
     assert np.array_equal(d_hits.cpu().numpy()[:, 0], ref["primId"])
 
 
