@@ -104,17 +104,27 @@ __global__ __launch_bounds__(kScheduleThreads) void k_persist_schedule(unsigned 
         }
         return slot;
     };
-    for (int i0 = 0; i0 < n; i0 += kScheduleThreads) {
-        const int i = i0 + t;
-        const bool valid = i < n;
-        unsigned e = 0u;
-        if (valid) {
-            const unsigned old = ema[i], c = cost[i];
-            e = old == 0u ? c : (RD_EMA_KEEP * old + c + RD_EMA_KEEP / 2) / (RD_EMA_KEEP + 1);
-            ema[i] = e;
-            cost[i] = 0u;
+    // four blocks per thread and round: the four pairs of loads are in flight together (one workgroup cannot hide a
+    // dependent global load per round behind anything else)
+    for (int i0 = 0; i0 < n; i0 += 4 * kScheduleThreads) {
+        unsigned old[4], c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = i0 + j * kScheduleThreads + t;
+            old[j] = i < n ? ema[i] : 0u;
+            c[j] = i < n ? cost[i] : 0u;
         }
-        waveAdd(hist, bucketOf(e), valid);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = i0 + j * kScheduleThreads + t;
+            const bool valid = i < n;
+            const unsigned e = old[j] == 0u ? c[j] : (RD_EMA_KEEP * old[j] + c[j] + RD_EMA_KEEP / 2) / (RD_EMA_KEEP + 1);
+            if (valid) {
+                ema[i] = e;
+                cost[i] = 0u;
+            }
+            waveAdd(hist, bucketOf(e), valid);
+        }
     }
     __syncthreads();
     if (t < 64) {  // exclusive prefix sum of the 64 bucket sizes
@@ -126,12 +136,20 @@ __global__ __launch_bounds__(kScheduleThreads) void k_persist_schedule(unsigned 
         base[t] = incl - v;
     }
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += kScheduleThreads) {  // order inside a bucket: ties are equally expensive
-        const int i = i0 + t;
-        const bool valid = i < n;
-        const int b = valid ? bucketOf(ema[i]) : 0;
-        const int pos = waveAdd(base, b, valid);
-        if (valid) order[pos] = i;
+    for (int i0 = 0; i0 < n; i0 += 4 * kScheduleThreads) {  // order inside a bucket: ties are equally expensive
+        unsigned e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = i0 + j * kScheduleThreads + t;
+            e[j] = i < n ? ema[i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = i0 + j * kScheduleThreads + t;
+            const bool valid = i < n;
+            const int pos = waveAdd(base, bucketOf(e[j]), valid);
+            if (valid) order[pos] = i;
+        }
     }
 }
 
