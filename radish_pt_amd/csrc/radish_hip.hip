@@ -46,11 +46,16 @@ struct rdh_ctx {
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
     float *posPlane = nullptr;  // denoisers: Camera::getPosition of every pixel (k_position_plane)
     long long posPlanePixels = 0;
-    unsigned *blockCost = nullptr;  // per-8x8-block cost of the previous persistent launch (k_persist_schedule)
-    unsigned *blockEma = nullptr;   // running mean of it over the launches so far
-    int *blockOrder = nullptr;
-    int costBlocks = 0;             // blocks the two arrays are sized / valid for
-    bool orderValid = false;
+    // Longest-paths-first block order (k_persist_schedule), off the critical path: launch n writes blockCost[n & 1]; the
+    // schedule of those costs runs on sideStream while launch n + 1 renders, and launch n + 2 reads its order from
+    // blockOrder[n & 1] (and reuses the cost buffer the schedule has zeroed).
+    unsigned *blockCost[2] = {nullptr, nullptr};
+    unsigned *blockEma = nullptr;   // running mean of the costs over the launches so far
+    int *blockOrder[2] = {nullptr, nullptr};
+    int costBlocks = 0;             // blocks the arrays are sized for
+    bool orderValid = false;        // false: restart the sequence (scene, camera size or partition changed)
+    int persistFrame = 0;           // persistent launches since the last restart
+    hipEvent_t evFrame = nullptr, evSched[2] = {nullptr, nullptr};
 
     // camera
     bool haveCamera = false;
@@ -270,6 +275,9 @@ int rdh_create(rdh_ctx **out, int device) {
         hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evFrame, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evSched[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evSched[1], hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&c->dCounters, sizeof(Counters)) != hipSuccess ||
         hipMalloc((void **)&c->dPersist, sizeof(PersistCounters)) != hipSuccess) {
         delete c;
@@ -301,9 +309,14 @@ void rdh_destroy(rdh_ctx *c) {
     if (c->dCounters) hipFree(c->dCounters);
     if (c->dPersist) hipFree(c->dPersist);
     if (c->posPlane) hipFree(c->posPlane);
-    if (c->blockCost) hipFree(c->blockCost);
+    if (c->sideStream) hipStreamSynchronize(c->sideStream);
+    for (int k = 0; k < 2; k++) {
+        if (c->blockCost[k]) hipFree(c->blockCost[k]);
+        if (c->blockOrder[k]) hipFree(c->blockOrder[k]);
+        if (c->evSched[k]) hipEventDestroy(c->evSched[k]);
+    }
     if (c->blockEma) hipFree(c->blockEma);
-    if (c->blockOrder) hipFree(c->blockOrder);
+    if (c->evFrame) hipEventDestroy(c->evFrame);
     if (c->evStart) hipEventDestroy(c->evStart);
     if (c->evStop) hipEventDestroy(c->evStop);
     if (c->evFork) hipEventDestroy(c->evFork);
@@ -531,37 +544,55 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         unsigned grid = groups < c->persistGrid ? groups : c->persistGrid;
         // longest-paths-first schedule from the previous launch's per-block costs (same partition and resolution only)
         if (c->costBlocks != pm.numBlocks) {
-            if (c->blockCost) hipFree(c->blockCost);
+            HIP_TRY(c, hipStreamSynchronize(c->sideStream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (int k = 0; k < 2; k++) {
+                if (c->blockCost[k]) hipFree(c->blockCost[k]);
+                if (c->blockOrder[k]) hipFree(c->blockOrder[k]);
+                c->blockCost[k] = nullptr;
+                c->blockOrder[k] = nullptr;
+            }
             if (c->blockEma) hipFree(c->blockEma);
             c->blockEma = nullptr;
-            if (c->blockOrder) hipFree(c->blockOrder);
-            c->blockCost = nullptr;
-            c->blockOrder = nullptr;
-            HIP_TRY(c, hipMalloc((void **)&c->blockCost, sizeof(unsigned) * (size_t)pm.numBlocks));
+            c->costBlocks = 0;
+            for (int k = 0; k < 2; k++) {
+                HIP_TRY(c, hipMalloc((void **)&c->blockCost[k], sizeof(unsigned) * (size_t)pm.numBlocks));
+                HIP_TRY(c, hipMalloc((void **)&c->blockOrder[k], sizeof(int) * (size_t)pm.numBlocks));
+            }
             HIP_TRY(c, hipMalloc((void **)&c->blockEma, sizeof(unsigned) * (size_t)pm.numBlocks));
             HIP_TRY(c, hipMemsetAsync(c->blockEma, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
-            HIP_TRY(c, hipMalloc((void **)&c->blockOrder, sizeof(int) * (size_t)pm.numBlocks));
-            HIP_TRY(c, hipMemsetAsync(c->blockCost, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
             c->costBlocks = pm.numBlocks;
             c->orderValid = false;
         }
+        if (!c->orderValid) {  // restart: no schedule in flight, both cost buffers zero, two launches in plain order
+            HIP_TRY(c, hipStreamSynchronize(c->sideStream));
+            for (int k = 0; k < 2; k++)
+                HIP_TRY(c, hipMemsetAsync(c->blockCost[k], 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
+            c->persistFrame = 0;
+            c->orderValid = true;
+        }
+        const int n = c->persistFrame++;
+        const int cb = n & 1;
         timeBegin(c);
-        const bool useOrder = c->orderValid && !(flags & RDH_PT_NO_SCHEDULE);
-        if (useOrder)
-            hipLaunchKernelGGL(k_persist_schedule, dim3(1), dim3(kScheduleThreads), 0, c->stream, c->blockCost, c->blockEma, c->blockOrder, pm.numBlocks);
-        else
-            HIP_TRY(c, hipMemsetAsync(c->blockCost, 0, sizeof(unsigned) * (size_t)pm.numBlocks, c->stream));
+        // the schedule of launch n - 2 (it ran beside launch n - 1) has written blockOrder[cb] and zeroed blockCost[cb]
+        if (n >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSched[cb], 0));
+        const bool useOrder = n >= 2 && !(flags & RDH_PT_NO_SCHEDULE);
         HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
-        const int *order = useOrder ? c->blockOrder : nullptr;
+        const int *order = useOrder ? c->blockOrder[cb] : nullptr;
         long pp = profBegin(c, flags);
         if (count)
             hipLaunchKernelGGL(k_pt_persistent<true>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
-                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost);
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
         else
             hipLaunchKernelGGL(k_pt_persistent<false>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
-                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost);
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
         profEnd(c, pp);
-        c->orderValid = true;
+        // this launch's costs -> running means -> block order for launch n + 2, on the side stream
+        HIP_TRY(c, hipEventRecord(c->evFrame, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evFrame, 0));
+        hipLaunchKernelGGL(k_persist_schedule, dim3(1), dim3(kScheduleThreads), 0, c->sideStream, c->blockCost[cb], c->blockEma,
+                           c->blockOrder[cb], pm.numBlocks);
+        HIP_TRY(c, hipEventRecord(c->evSched[cb], c->sideStream));
         return timeEnd(c, "pathTrace (persistent)");
     }
     timeBegin(c);
