@@ -12,9 +12,13 @@
 // additions, so the result is bit-identical to the megakernel and to the queue pipeline.  Wave-level scheduling only
 // decides WHEN a lane's next step runs:
 //   box steps   while enough lanes are walking,
-//   leaf tests  when >= RD_LEAF_NUM/RD_LEAF_DEN of the tracing lanes are parked on a leaf,
-//   shading     when >= RD_SHADE_MIN lanes wait for it (or nothing else can run),
-//   raygen      when >= RD_REFILL_MIN lanes are idle and pixels remain.
+//   leaf tests  when >= 1/RD_PT_LEAF_DEN of the tracing lanes are parked on a leaf,
+//   shading     when >= RD_SHADE_MIN 64ths of the busy lanes wait for it (or nothing else can run),
+//   raygen      when >= RD_PT_REFILL_MIN lanes are idle and pixels remain.
+// The three thresholds were re-tuned together at the end of round 1 (profiles/r01_f_experiment_thresholds.txt): 16 / 16 / 4
+// -> 32 / 6 / 3 is 4.8 % on the Cornell frame (3.34 -> 3.18 ms) and on the teapots frame (10.24 -> 9.75 ms), +1 % on the
+// 1-M-triangle 4K frame; one at a time each gave 1.5-2.4 %.  (Later shading batches are fuller and cost the same ~10 k clocks;
+// idle lanes are refilled sooner; triangles are tested a little earlier.)
 // Path state that is live only across phases (throughput, accumulators, the pending extension ray, …) sits in LDS,
 // 84 B per lane, so the traversal loop runs on the walker's registers alone.
 #pragma once
@@ -24,11 +28,17 @@
 namespace rd {
 
 #ifndef RD_SHADE_MIN
-#define RD_SHADE_MIN 16
+#define RD_SHADE_MIN 32
+#endif
+#ifndef RD_PT_REFILL_MIN
+#define RD_PT_REFILL_MIN 6
+#endif
+#ifndef RD_PT_LEAF_DEN  // k_pt_persistent only; the one-ray-per-lane kernels and the G-buffer keep RD_LEAF_NUM / RD_LEAF_DEN = 1 / 4
+#define RD_PT_LEAF_DEN 3
 #endif
 // ... and once the pixel supply has ended (64ths of the busy lanes).  In the drain a wave serialises the shading calls of its
-// remaining paths (≈10 k clocks each, whatever the lane count); waiting for half of them instead of a quarter measured
-// 1 % faster on the Cornell frame (3.40 -> 3.37 ms over three paired runs), neutral on teapots; 4 / 8: 3 % / 1.5 % slower.
+// remaining paths (≈10 k clocks each, whatever the lane count); with RD_SHADE_MIN at a quarter, waiting for half of them
+// in the drain measured 1 % faster on the Cornell frame, 4 / 8 64ths 3 % / 1.5 % slower; with RD_SHADE_MIN = 32 the two coincide.
 #ifndef RD_SHADE_MIN_DRAIN
 #define RD_SHADE_MIN_DRAIN 32
 #endif
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         // ---------------- raygen for idle lanes ----------------
         unsigned long long idleM = __ballot(state == PS_IDLE);
         int nIdle = __popcll(idleM);
-        if (!exhausted && nIdle >= RD_PIX_REFILL_MIN) {
+        if (!exhausted && nIdle >= RD_PT_REFILL_MIN) {
             PH_COUNT(14, idleM);
             int myRank = __popcll(idleM & laneMaskLt());
             int taken = 0;
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                     if (COUNT) ws.nodes += cr.visited;
                 }
             } else if (nStart > 0) {
-                const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
+                const int minWalk = (nStart * (RD_PT_LEAF_DEN - 1) + RD_PT_LEAF_DEN - 1) / RD_PT_LEAF_DEN;
                 do {
                     PH_COUNT(8, __ballot(walking));
                     waveSteps++;
