@@ -377,6 +377,39 @@ def test_1080p_variants_agree(gpu_ctx, cornell_full):
     assert c["closestRays"] >= W * H and np.isfinite(out["mega"][1]).all()
 
 
+def test_gbuffer_1080p_variants_agree(gpu_ctx):
+    """Full size (the oracle is too slow for 2 M primary rays of the teapots frame): the three G-buffer structures — lane refill
+    with the workgroup-per-ray launch for literal-class rays, lane refill tracing them in place, one lane per pixel — write
+    identical planes and count identical work, for the bench camera (a handful of such rays) and for an axis-aligned camera
+    (thousands: above the cap, none is set aside)."""
+    from radish_pt_amd import api, hostlib, scenes
+
+    W, H = 1920, 1080
+    sd = scenes.teapots(emissive_grid=(16, 32))
+    gpu_ctx.set_partition(0, 1, 64)
+    gpu_ctx.upload_scene(sd)
+    cams = [scenes.teapots_camera(W, H), hostlib.make_camera(W - 1, H - 1, eye=(0.0, 1.5, 9.0), rotation=(-90.0, 0.0, 0.0), fovy=19.0)]
+    assert _count_literal_primary_rays(cams[1]) > 256
+    for cam in cams:
+        w, h = int(cam["resolution"][0]), int(cam["resolution"][1])
+        gpu_ctx.set_camera(cam)
+        out = {}
+        for name, flags in (("defer", 0), ("in_place", api.RDH_PT_NO_DEFER), ("one_lane", api.RDH_PT_ONE_LANE_PER_PIXEL)):
+            gb = api.GBuffer()
+            gb.create(w, h)
+            gpu_ctx.counters_reset()
+            gpu_ctx.gbuffer_render(gb.c_struct(cam_fallback=cam), flags | api.RDH_PT_COUNT)
+            gpu_ctx.synchronize()
+            f = gb.frameIdx
+            out[name] = ([gb.albedo.cpu().numpy(), gb.normal[f].cpu().numpy(), gb.depth[f].cpu().numpy(),
+                          gb.primId[f].cpu().numpy(), gb.motion.cpu().numpy()], gpu_ctx.counters())
+        for name in ("defer", "in_place"):
+            for a, b, plane in zip(out[name][0], out["one_lane"][0], ("albedo", "normal", "depth", "primId", "motion")):
+                assert_bit_equal(a, b, f"{name} {plane}")
+            assert out[name][1] == out["one_lane"][1], name
+        assert out["defer"][1]["closestRays"] == w * h and (out["defer"][0][3] >= 0).mean() > 0.3
+
+
 def test_tile_partition_matches_frame(gpu_ctx, cornell_small):
     """N virtual ranks on one GPU: packed tile buffers → (simulated) all-gather → rdh_untile == single-GPU frame."""
     from radish_pt_amd import api, scenes
