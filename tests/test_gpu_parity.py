@@ -377,6 +377,33 @@ def test_1080p_variants_agree(gpu_ctx, cornell_full):
     assert c["closestRays"] >= W * H and np.isfinite(out["mega"][1]).all()
 
 
+def test_gbuffer_back_to_back_without_sync(gpu_ctx):
+    """rdh_gbuffer_render forks to an internal second stream and joins again; calls enqueued back to back (events re-recorded while
+    earlier waits are still pending) must leave exactly what synchronised calls leave."""
+    from radish_pt_amd import api, hostlib, scenes
+
+    sd = scenes.teapots(segments=12, bands=8, grid=2, emissive_grid=(4, 8))
+    gpu_ctx.set_partition(0, 1, 64)
+    gpu_ctx.upload_scene(sd)
+    W, H = 151, 91
+    cams = [hostlib.make_camera(W, H, eye=(0.0, 1.0 + 0.1 * f, 9.0), rotation=(-90.0, 0.0, 0.0), fovy=19.0) for f in range(12)]
+    ref = api.GBuffer()
+    ref.create(W, H)
+    gpu_ctx.set_camera(cams[-1])
+    gpu_ctx.gbuffer_render(ref.c_struct(cam_fallback=cams[-1]), 0)
+    gpu_ctx.synchronize()
+    gb = api.GBuffer()
+    gb.create(W, H)
+    for cam in cams:  # same buffers every time: a late write of an earlier call would show
+        gpu_ctx.set_camera(cam)
+        gpu_ctx.gbuffer_render(gb.c_struct(cam_fallback=cam), 0)
+    gpu_ctx.synchronize()
+    f = gb.frameIdx
+    for a, b, plane in ((gb.albedo, ref.albedo, "albedo"), (gb.normal[f], ref.normal[f], "normal"), (gb.depth[f], ref.depth[f], "depth"),
+                        (gb.primId[f], ref.primId[f], "primId")):
+        assert_bit_equal(a.cpu().numpy(), b.cpu().numpy(), plane)
+
+
 def test_gbuffer_1080p_variants_agree(gpu_ctx):
     """Full size (the oracle is too slow for 2 M primary rays of the teapots frame): the three G-buffer structures — lane refill
     with the workgroup-per-ray launch for literal-class rays, lane refill tracing them in place, one lane per pixel — write
