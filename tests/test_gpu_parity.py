@@ -469,64 +469,72 @@ def test_tile_partition_matches_frame(gpu_ctx, cornell_small):
     gpu_ctx.set_partition(0, 1, 64)
 
 
+def _restir_partition_run(gpu_ctx, sd, W, H, cams, world, tile, reuse):
+    """ReSTIR frames on `world` virtual ranks (one rdh_ctx each, all on this GPU): whole-frame G-buffer, rdh_restir_direct per
+    rank into its packed tiles, reservoir exchange (pack -> simulated all-gather -> unpack), rdh_untile.  Returns the frames and
+    every rank's `last` reservoirs after each frame."""
+    from radish_pt_amd import api
+
+    torch = _torch()
+    n = W * H
+    dev = api.DevScene()
+    ctxs = []
+    for rank in range(world):
+        c = gpu_ctx if world == 1 else api.Context(0)
+        c.upload_scene(sd)
+        c.set_partition(rank, world, tile)
+        c.set_camera(cams[0])
+        c.restir_init()
+        ctxs.append(c)
+    gb = api.GBuffer()
+    gb.create(W, H)
+    frames, resv = [], []
+    tpr = ctxs[0].tiles_per_rank()
+    imgs = [torch.zeros(n if world == 1 else tpr * tile * tile, 3, device="cuda") for _ in ctxs]
+    for f, cam in enumerate(cams):
+        dev.ctx = ctxs[0]
+        gb.render(dev, cam)  # whole frame regardless of the partition
+        for c, img in zip(ctxs, imgs):
+            c.set_camera(cam)
+            c.restir_direct(img, 0, 40 + f, gb.c_struct(cam), reuse)
+        if world == 1:
+            frames.append(imgs[0].cpu().numpy().copy())
+        else:
+            packs = []
+            for c in ctxs:
+                pk = torch.zeros(tpr * tile * tile, 9, device="cuda")
+                c.restir_exchange_pack(pk)
+                packs.append(pk)
+            gathered = torch.cat(packs).contiguous()
+            for c in ctxs:
+                c.restir_exchange_unpack(gathered)
+            frame = torch.zeros(n, 3, device="cuda")
+            ctxs[0].untile(torch.cat(imgs).contiguous(), frame)
+            ctxs[0].synchronize()
+            frames.append(frame.cpu().numpy().copy())
+        resv.append([c.restir_read(1).tobytes() for c in ctxs])
+        gb.update(cam)
+    for c in ctxs:
+        c.restir_free()
+        if c is not gpu_ctx:
+            c.close()
+    return frames, resv
+
+
 def test_restir_tile_partition_matches_frame(gpu_ctx):
     """ReSTIR DI on a tile partition (N virtual ranks, one rdh_ctx each, on one GPU): whole-frame G-buffer on every rank,
     pass 1 over the rank's tiles + 8-px apron, pass 2 local, reservoir exchange (pack -> simulated all-gather -> unpack)
     for next frame's temporal reuse.  Image and reservoirs must equal the single-GPU frame bit for bit, with a moving
     camera (motion vectors cross tile borders)."""
-    from radish_pt_amd import api, hostlib, scenes
+    from radish_pt_amd import hostlib, scenes
 
-    torch = _torch()
     sd = scenes.teapots(segments=12, bands=8, grid=2, emissive_grid=(4, 8))
     W, H = 150, 90  # not multiples of the tile size
-    n = W * H
     cams = [hostlib.make_camera(W, H, eye=(0.3 + 0.08 * f, 1.9, 7.4), rotation=(-91.5, -11.0, 0.0), fovy=19.0)
             for f in range(3)]
-    dev = api.DevScene()
-    dev.ctx = gpu_ctx
 
     def run(world, tile, reuse):
-        ctxs = []
-        for rank in range(world):
-            c = gpu_ctx if world == 1 else api.Context(0)
-            c.upload_scene(sd)
-            c.set_partition(rank, world, tile)
-            c.set_camera(cams[0])
-            c.restir_init()
-            ctxs.append(c)
-        gb = api.GBuffer()
-        gb.create(W, H)
-        frames, resv = [], []
-        tpr = ctxs[0].tiles_per_rank()
-        imgs = [torch.zeros(n if world == 1 else tpr * tile * tile, 3, device="cuda") for _ in ctxs]
-        for f, cam in enumerate(cams):
-            dev.ctx = ctxs[0]
-            gb.render(dev, cam)  # whole frame regardless of the partition
-            for c, img in zip(ctxs, imgs):
-                c.set_camera(cam)
-                c.restir_direct(img, 0, 40 + f, gb.c_struct(cam), reuse)
-            if world == 1:
-                frames.append(imgs[0].cpu().numpy().copy())
-            else:
-                packs = []
-                for c in ctxs:
-                    pk = torch.zeros(tpr * tile * tile, 9, device="cuda")
-                    c.restir_exchange_pack(pk)
-                    packs.append(pk)
-                gathered = torch.cat(packs).contiguous()
-                for c in ctxs:
-                    c.restir_exchange_unpack(gathered)
-                frame = torch.zeros(n, 3, device="cuda")
-                ctxs[0].untile(torch.cat(imgs).contiguous(), frame)
-                ctxs[0].synchronize()
-                frames.append(frame.cpu().numpy().copy())
-            resv.append([c.restir_read(1).tobytes() for c in ctxs])
-            gb.update(cam)
-        for c in ctxs:
-            c.restir_free()
-            if c is not gpu_ctx:
-                c.close()
-        return frames, resv
+        return _restir_partition_run(gpu_ctx, sd, W, H, cams, world, tile, reuse)
 
     for reuse in (3, 1, 2):
         ref_frames, ref_resv = run(1, 64, reuse)
@@ -537,6 +545,30 @@ def test_restir_tile_partition_matches_frame(gpu_ctx):
                 assert_bit_equal(frames[f], ref_frames[f], f"ReSTIR world={world} tile={tile} reuse={reuse} frame {f}")
                 for r in range(world):
                     assert resv[f][r] == ref_resv[f][0], f"reservoirs world={world} rank {r} frame {f}"
+    gpu_ctx.set_partition(0, 1, 64)
+
+
+def test_restir_1080p_partition_and_determinism(gpu_ctx):
+    """BASELINE config 4 at full size, in config 5's structure: teapots + 1 024 emissive triangles, 1920x1080, ReSTIR DI M = 32
+    with temporal + spatial reuse, two frames with a moving camera.  The oracle is too slow here, so the properties: the
+    two-pass ReSTIR is deterministic (the reference's single kernel is not), and 8 virtual ranks with the
+    reservoir exchange give the single-GPU frames and reservoirs bit for bit."""
+    from radish_pt_amd import hostlib, scenes
+
+    sd = scenes.teapots(emissive_grid=(16, 32))
+    W, H = 1920, 1080
+    cams = [hostlib.make_camera(W, H, eye=(0.3 + 0.02 * f, 1.9, 7.4), rotation=(-91.5, -11.0, 0.0), fovy=19.0) for f in range(2)]
+    a_frames, a_resv = _restir_partition_run(gpu_ctx, sd, W, H, cams, 1, 64, 3)
+    b_frames, b_resv = _restir_partition_run(gpu_ctx, sd, W, H, cams, 1, 64, 3)
+    for f in range(len(cams)):
+        assert_bit_equal(b_frames[f], a_frames[f], f"second run, frame {f}")
+        assert b_resv[f] == a_resv[f]
+        assert np.isfinite(a_frames[f]).all() and a_frames[f].mean() > 0.05
+    frames, resv = _restir_partition_run(gpu_ctx, sd, W, H, cams, 8, 64, 3)
+    for f in range(len(cams)):
+        assert_bit_equal(frames[f], a_frames[f], f"8 ranks, frame {f}")
+        for r in range(8):
+            assert resv[f][r] == a_resv[f][0], f"reservoirs of rank {r}, frame {f}"
     gpu_ctx.set_partition(0, 1, 64)
 
 
