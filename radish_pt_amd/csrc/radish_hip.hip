@@ -761,21 +761,20 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
     a.faithfulRIS = p->faithfulRIS;
     // On a tile partition with spatial reuse, pass 1 also covers an 8-pixel apron around this rank's tiles.
     int apronBlocks = 0;
-    unsigned grid1 = gridFor(pm);
     if (c->world > 1 && (p->reuseMask & 2)) {
         int bpe = pm.tile / 8 + 2;
         apronBlocks = pm.tilesPerRank * bpe * bpe;
-        unsigned work = (unsigned)(apronBlocks + 3) / 4;
-        grid1 = ((work + 7u) / 8u) * 8u;
     }
+    const unsigned p1Threads = 64;  // single-wave workgroups, one 8x8 block each (kernels_restir.h)
+    const unsigned grid1 = (((unsigned)(apronBlocks > 0 ? apronBlocks : pm.numBlocks) + 7u) / 8u) * 8u;
     timeBegin(c);
     // One lane per pixel: a persistent lane-refill version of this pass (as for the G-buffer) was built and measured slower
     // (3.21 ms against 2.90 ms on the teapots config): the 32-candidate RIS dominates, runs at full wave width here and at
     // 32-48 lanes per batch there, and the state machine's 146 VGPRs cost two of this kernel's five waves per SIMD.
     if (flags & RDH_PT_COUNT)
-        hipLaunchKernelGGL(k_restir_pass1<true>, dim3(grid1), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
+        hipLaunchKernelGGL(k_restir_pass1<true>, dim3(grid1), dim3(p1Threads), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
     else
-        hipLaunchKernelGGL(k_restir_pass1<false>, dim3(grid1), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
+        hipLaunchKernelGGL(k_restir_pass1<false>, dim3(grid1), dim3(p1Threads), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
     if (p->reuseMask & 2)
         hipLaunchKernelGGL(k_restir_pass2, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, pm, iter, a, d_direct);
     rc = timeEnd(c, "ReSTIR Direct");
