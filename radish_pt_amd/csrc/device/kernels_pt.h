@@ -55,6 +55,16 @@ RD_DEV Pix mapPixel(const PixelMap &pm, unsigned block, unsigned lane) {
     return p;
 }
 
+// The pixel of this lane when the launch has one single-wave workgroup per 8x8 block (64 threads, gridBlocks(pm) workgroups):
+// XCD x gets a contiguous range of blocks.  (Four-wave workgroups kept their slots until the slowest of their waves had ended.)
+RD_DEV Pix mapWavePixel(const PixelMap &pm) {
+    unsigned blk;
+    const bool ok = xcdSwizzle(blockIdx.x, (unsigned)pm.numBlocks, blk);
+    Pix px = mapPixel(pm, ok ? blk : 0xffffffffu / 64u, threadIdx.x & 63u);
+    px.valid = px.valid && ok;
+    return px;
+}
+
 RD_DEV v3 load3(const float *img, int i) { return mk3(img[3 * i], img[3 * i + 1], img[3 * i + 2]); }
 RD_DEV void store3(float *img, int i, v3 v) {
     img[3 * i] = v.x;
@@ -103,11 +113,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void k_path_trace_mega(DScene s, DCamera cam, PixelMap pm, int looper, int iter,
                                                          int maxDepth, float *__restrict__ directIllum,
                                                          float *__restrict__ indirectIllum) {
-    unsigned wg;
-    bool wgValid = xcdSwizzle(blockIdx.x, (unsigned)(pm.numBlocks + 3) >> 2, wg);
-    unsigned lane = threadIdx.x & 63u;
-    Pix px = mapPixel(pm, wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u, lane);
-    px.valid = px.valid && wgValid;
+    Pix px = mapWavePixel(pm);  // single-wave workgroups: 64 threads, one 8x8 block each
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
 
@@ -205,11 +211,7 @@ __global__ __launch_bounds__(256) void k_path_trace_mega(DScene s, DCamera cam, 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_path_trace_direct(DScene s, DCamera cam, PixelMap pm, int looper, int iter,
                                                            float *__restrict__ directIllum) {
-    unsigned wg;
-    bool wgValid = xcdSwizzle(blockIdx.x, (unsigned)(pm.numBlocks + 3) >> 2, wg);
-    unsigned lane = threadIdx.x & 63u;
-    Pix px = mapPixel(pm, wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u, lane);
-    px.valid = px.valid && wgValid;
+    Pix px = mapWavePixel(pm);  // single-wave workgroups: 64 threads, one 8x8 block each
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
     if (px.valid) {
@@ -263,11 +265,7 @@ struct GBufPtrs {
 };
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_gbuffer(DScene s, DCamera cam, DCamera lastCam, PixelMap pm, GBufPtrs gb) {
-    unsigned wg;
-    bool wgValid = xcdSwizzle(blockIdx.x, (unsigned)(pm.numBlocks + 3) >> 2, wg);
-    unsigned lane = threadIdx.x & 63u;
-    Pix px = mapPixel(pm, wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u, lane);
-    px.valid = px.valid && wgValid;
+    Pix px = mapWavePixel(pm);  // single-wave workgroups: 64 threads, one 8x8 block each
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nHits = 0;
     if (px.valid) {

@@ -169,6 +169,8 @@ unsigned gridFor(const PixelMap &pm) {
     return ((work + 7u) / 8u) * 8u;
 }
 
+unsigned gridBlocks(const PixelMap &pm) { return (((unsigned)pm.numBlocks + 7u) / 8u) * 8u; }  // single-wave workgroups
+
 int requireReady(rdh_ctx *c) {
     if (!c) return RDH_ERR_ARGS;
     if (!c->haveScene) return fail(c, RDH_ERR_NO_SCENE, "no scene uploaded (rdh_scene_upload)");
@@ -598,10 +600,10 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
     timeBegin(c);
     long pe = profBegin(c, flags);
     if (count)
-        hipLaunchKernelGGL(k_path_trace_mega<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
+        hipLaunchKernelGGL(k_path_trace_mega<true>, dim3(gridBlocks(pm)), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper,
                            iter, maxDepth, d_direct, d_indirect);
     else
-        hipLaunchKernelGGL(k_path_trace_mega<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
+        hipLaunchKernelGGL(k_path_trace_mega<false>, dim3(gridBlocks(pm)), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper,
                            iter, maxDepth, d_direct, d_indirect);
     profEnd(c, pe);
     return timeEnd(c, "pathTrace");
@@ -615,10 +617,10 @@ int rdh_path_trace_direct(rdh_ctx *c, float *d_direct, int iter, int looper, uin
     PixelMap pm = makePixelMap(c);
     timeBegin(c);
     if (flags & RDH_PT_COUNT)
-        hipLaunchKernelGGL(k_path_trace_direct<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
+        hipLaunchKernelGGL(k_path_trace_direct<true>, dim3(gridBlocks(pm)), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper,
                            iter, d_direct);
     else
-        hipLaunchKernelGGL(k_path_trace_direct<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper,
+        hipLaunchKernelGGL(k_path_trace_direct<false>, dim3(gridBlocks(pm)), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper,
                            iter, d_direct);
     return timeEnd(c, "pathTraceDirect");
 }
@@ -648,9 +650,9 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
     if (flags & RDH_PT_ONE_LANE_PER_PIXEL) {  // one lane per pixel for the whole launch (the reference's structure)
         timeBegin(c);
         if (flags & RDH_PT_COUNT)
-            hipLaunchKernelGGL(k_gbuffer<true>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p);
+            hipLaunchKernelGGL(k_gbuffer<true>, dim3(gridBlocks(pm)), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p);
         else
-            hipLaunchKernelGGL(k_gbuffer<false>, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p);
+            hipLaunchKernelGGL(k_gbuffer<false>, dim3(gridBlocks(pm)), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p);
         return timeEnd(c, "renderGBuffer");
     }
     // persistent launch with lane refill: as many single-wave workgroups as stay resident, never more than there is work
