@@ -21,12 +21,19 @@ namespace rd {
 
 constexpr int kMaxWaveDepth = 32;  // 4 + 7*depth Sobol dimensions <= 200 → depth <= 28
 
+// Every counter sits on its own 128-byte line: same-address returning atomics serialise at ~12 ns each, and counters that share
+// a line share that queue — the four class counters of k_wf_classify, side by side in one line, made it the slowest kernel of
+// the sorted pipeline (0.87 ms per launch on the teapots frame).
+struct alignas(128) WaveCounter {
+    int v;
+    int pad[31];
+};
 struct WaveCounters {
-    int rayCount[kMaxWaveDepth + 2];     // rays of bounce k (written by raygen / shade(k-1))
-    int shadowCount[kMaxWaveDepth + 2];  // shadow rays emitted by shade(k)
-    int hitCount[kMaxWaveDepth + 2][4];  // hit records of bounce k per shading class
-    int traceHead[kMaxWaveDepth + 2];
-    int shadeHead[kMaxWaveDepth + 2][4];
+    WaveCounter rayCount[kMaxWaveDepth + 2];     // rays of bounce k (written by raygen / shade(k-1))
+    WaveCounter shadowCount[kMaxWaveDepth + 2];  // shadow rays emitted by shade(k)
+    WaveCounter hitCount[kMaxWaveDepth + 2][4];  // hit records of bounce k per shading class
+    WaveCounter traceHead[kMaxWaveDepth + 2];
+    WaveCounter shadeHead[kMaxWaveDepth + 2][4];
 };
 
 struct WaveWorkspace {
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelM
     // Bounce 0's queue is the identity over this launch's slots (-1 marks pixels outside the frame): no compaction,
     // no atomic.
     if (block < (unsigned)pm.numBlocks) w.rayq[0][p] = valid ? p : -1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.ctr->rayCount[0] = pm.numBlocks * 64;
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.ctr->rayCount[0].v = pm.numBlocks * 64;
 }
 
 // ---- trace(k): shadow rays of bounce k (from shade(k-1)) + closest hits of bounce k ---------------------------
@@ -108,8 +115,8 @@ __global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelM
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int k) {
     WaveCounters *c = w.ctr;
-    const int nShadow = (k > 0) ? c->shadowCount[k - 1] : 0;
-    const int nRay = c->rayCount[k];
+    const int nShadow = (k > 0) ? c->shadowCount[k - 1].v : 0;
+    const int nRay = c->rayCount[k].v;
     const int total = nShadow + nRay;
     const int *rayq = w.rayq[k & 1];
     WalkStats ws{0, 0};
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
             int taken = 0;  // items handed out so far in this refill (wave-uniform)
             while (taken < nIdle && !exhausted) {
                 if (resNext == resEnd) {
-                    resNext = wavePull(&c->traceHead[k]);
+                    resNext = wavePull(&c->traceHead[k].v);
                     resEnd = resNext + kPacket;
                     if (resNext >= total) {
                         exhausted = true;
@@ -296,26 +303,55 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
 
 // ---- classify(k) (material sort only): bin bounce k's hit records by BSDF type ------------------------------------
 // Four queues: 0 = terminal (miss / emitter / unknown), 1 = Lambertian, 2 = metallic workflow, 3 = dielectric.
-// One ballot + one atomic per wave per non-empty class per 64 records.
+// One ballot per 64 records and class, one atomic per wave per non-empty class per 256 records.
 __global__ __launch_bounds__(256) void k_wf_classify(DScene s, WaveWorkspace w, int k) {
     WaveCounters *c = w.ctr;
-    const int n = c->rayCount[k];
+    const int n = c->rayCount[k].v;
     const int *rayq = w.rayq[k & 1];
-    const int stride = gridWaves() * 64;
-    for (int i = globalWave() * 64 + int(threadIdx.x & 63u); i - int(threadIdx.x & 63u) < n; i += stride) {
-        int p = (i < n) ? rayq[i] : -1;
-        int cls = -1;
-        if (p >= 0) {
-            int prim = w.hit[p].x;
-            cls = 0;
-            if (prim != -1) {
-                int matId = __float_as_int(s.tris[prim].c.y);
-                int type = __float_as_int(s.mats[matId].a.x);
-                cls = (type == Lambertian) ? 1 : (type == MetallicWorkflow ? 2 : (type == Dielectric ? 3 : 0));
+    const int lane = int(threadIdx.x & 63u);
+    // four chunks of 64 records per wave and round: their dependent reads (queue -> hit -> triangle -> material) are in flight
+    // together, and each class costs ONE returning atomic per 256 records (they serialise chip-wide per counter)
+    constexpr int C = 4;
+    const int stride = gridWaves() * 64 * C;
+    for (int i0 = globalWave() * 64 * C; i0 < n; i0 += stride) {
+        int p[C], cls[C];
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            const int i = i0 + j * 64 + lane;
+            p[j] = (i < n) ? rayq[i] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            cls[j] = -1;
+            if (p[j] >= 0) {
+                int prim = w.hit[p[j]].x;
+                cls[j] = 0;
+                if (prim != -1) {
+                    int matId = __float_as_int(s.tris[prim].c.y);
+                    int type = __float_as_int(s.mats[matId].a.x);
+                    cls[j] = (type == Lambertian) ? 1 : (type == MetallicWorkflow ? 2 : (type == Dielectric ? 3 : 0));
+                }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) waveAppend(cls == q, p, w.hitq[q], &c->hitCount[k][q]);
+        for (int q = 0; q < 4; q++) {
+            unsigned long long m[C];
+            int total = 0;
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                m[j] = __ballot(cls[j] == q);
+                total += __popcll(m[j]);
+            }
+            if (total == 0) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&c->hitCount[k][q].v, total);
+            base = __shfl(base, 0, 64);
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                if (cls[j] == q) w.hitq[q][base + __popcll(m[j] & laneMaskLt())] = p[j];
+                base += __popcll(m[j]);
+            }
+        }
     }
 }
 
@@ -325,11 +361,11 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
     WaveCounters *c = w.ctr;
     const int lane = int(threadIdx.x & 63u);
     for (int q = 0; q < (sorted ? 4 : 1); q++) {
-        const int n = sorted ? c->hitCount[k][q] : c->rayCount[k];
+        const int n = sorted ? c->hitCount[k][q].v : c->rayCount[k].v;
         const int *hitq = sorted ? w.hitq[q] : w.rayq[k & 1];
         for (int base = globalWave() * kPacket, sub = 0;;) {
             if (sub == kPacket) {
-                base = wavePull(&c->shadeHead[k][q]);
+                base = wavePull(&c->shadeHead[k][q].v);
                 sub = 0;
             }
             if (base + sub >= n) break;
@@ -432,8 +468,8 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                     emitRay = true;
                 } while (false);
             }
-            waveAppend(emitShadow, p, w.shadowq, &c->shadowCount[k]);
-            waveAppend(emitRay, p, w.rayq[(k + 1) & 1], &c->rayCount[k + 1]);
+            waveAppend(emitShadow, p, w.shadowq, &c->shadowCount[k].v);
+            waveAppend(emitRay, p, w.rayq[(k + 1) & 1], &c->rayCount[k + 1].v);
         }
     }
 }
