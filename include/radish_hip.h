@@ -95,6 +95,8 @@ typedef struct rdh_counters {
 #define RDH_PT_ONE_LANE_PER_PIXEL 64u /* rdh_gbuffer_render: the one-lane-per-pixel kernel (k_gbuffer) instead of the persistent
                                          lane-refill one (k_gbuffer_persistent)                                              */
 #define RDH_PT_MEGA_GBUFFER RDH_PT_ONE_LANE_PER_PIXEL
+#define RDH_PT_WG_PER_RAY 256u /* rdh_trace_closest / rdh_trace_occluded: one 1 024-thread workgroup per ray (the routine the
+                                  G-buffer uses for literal-class rays); for tests            */
 #define RDH_PT_NO_DEFER 128u   /* rdh_gbuffer_render: trace literal-class rays where they are generated (one wave each)
                                   instead of setting them aside for the workgroup-per-ray launch (k_gbuffer_literal)   */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */

@@ -195,4 +195,47 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
     if (COUNT) flushCounters(s.counters, ANY ? 0u : nRays, ANY ? nRays : 0u, nHits, ws);
 }
 
+// One WORKGROUP per ray (wg_trace.h) over a ray batch: RDH_PT_WG_PER_RAY on the ray-batch entries.  This is how the G-buffer
+// traces its literal-class rays; as an entry of its own it lets the tests put every kind of ray
+// through wgTraceWhole (closest and any-hit) and compare records and counters with the oracle.  Far slower than the walkers
+// for ordinary rays: 16 waves per ray.
+template <bool COUNT, bool ANY>
+__global__ __launch_bounds__(kWgTraceThreads) void k_trace_wg(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,
+                                                              int *__restrict__ occluded) {
+    __shared__ WgTraceShared sh;
+    for (long long i = (long long)blockIdx.x; i < n; i += (long long)gridDim.x) {
+        const v3 a = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+        const v3 b = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+        Ray ray;
+        float tmax;
+        if (ANY) {  // testOcclusion(a, b) (scene.h:303-315)
+            v3 dir = b - a;
+            float dist = length(dir);
+            dir = dir / dist;
+            ray = makeOffsetedRay(a, dir);
+            tmax = dist - 1e-4f;
+        } else {
+            ray = Ray{a, b};
+            tmax = 3.402823466e+38f;
+        }
+        const RaySlab rs = makeRaySlab(ray);
+        CoopTrace ct = wgTraceWhole<ANY>(s, s.nodes[getMTBVHId(-ray.d)], rs, tmax, sh);
+        if (threadIdx.x == 0) {
+            if (ANY) {
+                occluded[i] = ct.found ? 1 : 0;
+            } else {
+                const bool hit = ct.hitPrim != -1;
+                hits[i] = make_int4(ct.hitPrim, __float_as_int(hit ? ct.bary.x : 0.f), __float_as_int(hit ? ct.bary.y : 0.f),
+                                    __float_as_int(hit ? ct.tmax : 3.402823466e+38f));
+            }
+            if (COUNT) {
+                atomicAdd(ANY ? &s.counters->anyRays : &s.counters->closestRays, 1ull);
+                atomicAdd(&s.counters->nodeVisits, (unsigned long long)ct.nodes);
+                atomicAdd(&s.counters->triTests, (unsigned long long)ct.tris);
+                if (!ANY && ct.hitPrim != -1) atomicAdd(&s.counters->closestHits, 1ull);
+            }
+        }
+    }
+}
+
 }  // namespace rd

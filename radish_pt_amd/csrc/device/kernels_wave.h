@@ -53,7 +53,6 @@ struct WaveWorkspace {
     WaveCounters *ctr;
 };
 
-RD_DEV unsigned long long laneMaskLt() { return (1ull << (threadIdx.x & 63u)) - 1ull; }
 
 // Append `item` for every lane with pred==true: one atomic per wave, order inside the wave preserved.
 RD_DEV void waveAppend(bool pred, int item, int *queue, int *count) {

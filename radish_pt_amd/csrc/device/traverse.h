@@ -299,6 +299,8 @@ RD_DEV CoopResult coopWalk(const NodeRec *nodes, int node, int end, const RaySla
     return r;
 }
 
+RD_DEV unsigned long long laneMaskLt() { return (1ull << (threadIdx.x & 63u)) - 1ull; }  // lanes below this one
+
 // Broadcast lane L's ray to the whole wave (SGPRs).
 RD_DEV RaySlab readlaneRay(const RaySlab &rs, int L) {
     RaySlab u;

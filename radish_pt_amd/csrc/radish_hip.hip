@@ -822,6 +822,16 @@ int rdh_restir_read(rdh_ctx *c, int which, void *hostOut) {
 extern "C++" {
 static int walkPersistent(rdh_ctx *c, const float *d_rays, int64_t n, int4 *d_hits, int *d_occ, uint32_t flags, const char *what) {
     const int any = d_occ ? 1 : 0;
+    if (flags & RDH_PT_WG_PER_RAY) {  // one workgroup per ray (device/kernels_walk.h, k_trace_wg): test access to wgTraceWhole
+        const unsigned g = (unsigned)(n < 4096 ? n : 4096);
+        const bool cnt = (flags & RDH_PT_COUNT) != 0;
+        timeBegin(c);
+        if (any && cnt) hipLaunchKernelGGL((k_trace_wg<true, true>), dim3(g), dim3(kWgTraceThreads), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ);
+        else if (any) hipLaunchKernelGGL((k_trace_wg<false, true>), dim3(g), dim3(kWgTraceThreads), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ);
+        else if (cnt) hipLaunchKernelGGL((k_trace_wg<true, false>), dim3(g), dim3(kWgTraceThreads), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ);
+        else hipLaunchKernelGGL((k_trace_wg<false, false>), dim3(g), dim3(kWgTraceThreads), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ);
+        return timeEnd(c, what);
+    }
     if (c->walkGrid[any] == 0) {
         int perCU = 0, cus = 0;
         if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, true>), 64, 0));
@@ -852,7 +862,7 @@ int rdh_trace_closest(rdh_ctx *c, const float *d_rays, int64_t n, rdh_hit *d_hit
     if (n < 0 || (n > 0 && (!d_rays || !d_hits))) return fail(c, RDH_ERR_ARGS, "rdh_trace_closest: bad arguments");
     if (n == 0) return RDH_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (flags & RDH_PT_PERSISTENT) return walkPersistent(c, d_rays, n, (int4 *)d_hits, nullptr, flags, "trace_closest (persistent)");
+    if (flags & (RDH_PT_PERSISTENT | RDH_PT_WG_PER_RAY)) return walkPersistent(c, d_rays, n, (int4 *)d_hits, nullptr, flags, "trace_closest (persistent)");
     unsigned grid = (unsigned)((n + 255) / 256);
     timeBegin(c);
     if (flags & RDH_PT_COUNT)
@@ -868,7 +878,7 @@ int rdh_trace_occluded(rdh_ctx *c, const float *d_seg, int64_t n, int32_t *d_occ
     if (n < 0 || (n > 0 && (!d_seg || !d_occ))) return fail(c, RDH_ERR_ARGS, "rdh_trace_occluded: bad arguments");
     if (n == 0) return RDH_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (flags & RDH_PT_PERSISTENT) return walkPersistent(c, d_seg, n, nullptr, d_occ, flags, "trace_occluded (persistent)");
+    if (flags & (RDH_PT_PERSISTENT | RDH_PT_WG_PER_RAY)) return walkPersistent(c, d_seg, n, nullptr, d_occ, flags, "trace_occluded (persistent)");
     unsigned grid = (unsigned)((n + 255) / 256);
     timeBegin(c);
     if (flags & RDH_PT_COUNT)

@@ -111,6 +111,50 @@ def test_trace_empty_and_ragged(cornell_gpu, cornell_small):
     assert np.array_equal(d_hits.cpu().numpy()[:, 0], ref["primId"])
 
 
+def test_workgroup_per_ray_trace_bit_exact(cornell_gpu, cornell_small):
+    """wgTraceWhole (device/wg_trace.h), the routine behind k_gbuffer_literal, on every kind of ray: one
+    1 024-thread workgroup per ray, closest-hit and any-hit, random rays and axis-parallel / tiny-component ones (the box
+    test's special cases, bvh.h:138-148).  Records and work counters equal the oracle's sequential walk."""
+    from radish_pt_amd import api, layouts as L
+
+    torch = _torch()
+    o = _oracle(cornell_small)
+    rays = random_rays(1500, seed=21)
+    rays[::4, 3:] = np.array([0.0, 0.0, -1.0], np.float32)
+    rays[1::9, 3:] = np.array([0.0, 1.0, 0.0], np.float32)
+    d = rays[2::11, 3:].copy()
+    d[:, 0] = 3e-7
+    rays[2::11, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    before = o.stats()
+    ref = o.trace_closest(rays)
+    after = o.stats()
+    d_hits = torch.zeros(len(rays), 4, dtype=torch.int32, device="cuda")
+    cornell_gpu.counters_reset()
+    cornell_gpu.trace_closest(_dev(rays), d_hits, api.RDH_PT_COUNT | api.RDH_PT_WG_PER_RAY)
+    got = d_hits.cpu().numpy().view(L.HIT_DTYPE).reshape(-1)
+    assert np.array_equal(got["primId"], ref["primId"])
+    for f in ("u", "v", "t"):
+        assert_bit_equal(got[f], ref[f], f"hit.{f}")
+    ct = cornell_gpu.counters()
+    for k in ("closestRays", "nodeVisits", "triTests", "closestHits"):
+        assert ct[k] == after[k] - before[k], k
+    assert (ref["primId"] >= 0).mean() > 0.3
+
+    seg = random_segments(1500, seed=8)
+    seg[::4, 3:5] = seg[::4, 0:2]              # along z
+    seg[1::7, 4:6] = seg[1::7, 1:3]            # along x
+    before = o.stats()
+    ref_o = o.trace_occluded(seg)
+    after = o.stats()
+    d_out = torch.full((len(seg),), -1, dtype=torch.int32, device="cuda")
+    cornell_gpu.counters_reset()
+    cornell_gpu.trace_occluded(_dev(seg), d_out, api.RDH_PT_COUNT | api.RDH_PT_WG_PER_RAY)
+    assert np.array_equal(d_out.cpu().numpy(), ref_o)
+    ct = cornell_gpu.counters()
+    for k in ("anyRays", "nodeVisits", "triTests"):
+        assert ct[k] == after[k] - before[k], k
+    assert 0.05 < ref_o.mean() < 0.95
+
 # ---------------------------------------------------------------------------------------------------------------------
 # pathTrace: megakernel and wavefront, several frames of accumulation
 # ---------------------------------------------------------------------------------------------------------------------
