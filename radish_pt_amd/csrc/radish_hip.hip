@@ -44,6 +44,7 @@ struct rdh_ctx {
     unsigned persistGrid = 0;
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
+    unsigned wfGrid[4] = {0, 0, 0, 0};  // resident workgroups of k_wf_trace<false> / <true>, k_wf_classify, k_wf_shade
     float *posPlane = nullptr;  // denoisers: Camera::getPosition of every pixel (k_position_plane)
     long long posPlanePixels = 0;
     // Longest-paths-first block order (k_persist_schedule), off the critical path: launch n writes blockCost[n & 1]; the
@@ -237,13 +238,28 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     WaveWorkspace &w = c->wf;
     HIP_TRY(c, hipMemsetAsync(w.ctr, 0, sizeof(WaveCounters), c->stream));
     hipLaunchKernelGGL(k_wf_raygen, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, w, looper);
+    // Persistent kernels whose waves take a STATIC first packet: every workgroup must be resident from the start, or the
+    // surplus ones run their static packets after everybody else has finished (k_wf_trace fits 6 waves per SIMD, k_wf_shade 4:
+    // the fixed grid of 8 per SIMD used before left a quarter / half of the waves waiting for a slot).
+    if (c->wfGrid[0] == 0) {
+        int cus = 0, per[4] = {0, 0, 0, 0};
+        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[0], k_wf_trace<false>, 256, 0));
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[1], k_wf_trace<true>, 256, 0));
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[2], k_wf_classify, 256, 0));
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[3], k_wf_shade, 256, 0));
+        for (int q = 0; q < 4; q++) {
+            unsigned g = (unsigned)((per[q] < 1 ? 1 : per[q]) * cus);
+            c->wfGrid[q] = g < kPersistentGrid ? g : kPersistentGrid;
+        }
+    }
     for (int k = 0; k <= maxDepth; k++) {
         long pe = profBegin(c, flags);
-        if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
-        else hipLaunchKernelGGL(k_wf_trace<false>, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
+        if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(c->wfGrid[1]), dim3(256), 0, c->stream, c->ds, w, k);
+        else hipLaunchKernelGGL(k_wf_trace<false>, dim3(c->wfGrid[0]), dim3(256), 0, c->stream, c->ds, w, k);
         profEnd(c, pe);
-        if (sort) hipLaunchKernelGGL(k_wf_classify, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k);
-        hipLaunchKernelGGL(k_wf_shade, dim3(kPersistentGrid), dim3(256), 0, c->stream, c->ds, w, k, maxDepth, sort ? 1 : 0);
+        if (sort) hipLaunchKernelGGL(k_wf_classify, dim3(c->wfGrid[2]), dim3(256), 0, c->stream, c->ds, w, k);
+        hipLaunchKernelGGL(k_wf_shade, dim3(c->wfGrid[3]), dim3(256), 0, c->stream, c->ds, w, k, maxDepth, sort ? 1 : 0);
     }
     hipLaunchKernelGGL(k_wf_finish, dim3(gridFor(pm)), dim3(256), 0, c->stream, pm, w, iter, d_direct, d_indirect);
     return RDH_OK;
