@@ -65,6 +65,19 @@ RD_DEV void waveAppend(bool pred, int item, int *queue, int *count) {
     if (pred) queue[base + __popcll(mask & laneMaskLt())] = item;
 }
 
+// The same for the two 64-record halves of a 128-record packet at once: ONE returning atomic (they serialise chip-wide per
+// counter at ~12 ns; k_wf_shade's two appends per 64 records were most of its time).
+RD_DEV void waveAppend2(bool pred0, int item0, bool pred1, int item1, int *queue, int *count) {
+    const unsigned long long m0 = __ballot(pred0), m1 = __ballot(pred1);
+    const int n0 = __popcll(m0), total = n0 + __popcll(m1);
+    if (total == 0) return;
+    int base = 0;
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(count, total);
+    base = __shfl(base, 0, 64);
+    if (pred0) queue[base + __popcll(m0 & laneMaskLt())] = item0;
+    if (pred1) queue[base + n0 + __popcll(m1 & laneMaskLt())] = item1;
+}
+
 // Work distribution for the persistent kernels.  Same-address returning atomics serialise chip-wide at ~12 ns each
 // (MI355X_MICROARCH.md "dequeue"/"fanin"), so (a) every wave's FIRST packet is static — wave g takes items
 // [g*kPacket, (g+1)*kPacket) — and the shared head only hands out what lies beyond gridWaves*kPacket, and (b) a pull
@@ -362,6 +375,9 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
     for (int q = 0; q < (sorted ? 4 : 1); q++) {
         const int n = sorted ? c->hitCount[k][q].v : c->rayCount[k].v;
         const int *hitq = sorted ? w.hitq[q] : w.rayq[k & 1];
+        static_assert(kPacket == 128, "k_wf_shade appends once per packet of two 64-record halves");
+        int pendP = -1;  // first half of the packet: held until the second half has been shaded, then appended together
+        bool pendShadow = false, pendRay = false;
         for (int base = globalWave() * kPacket, sub = 0;;) {
             if (sub == kPacket) {
                 base = wavePull(&c->shadeHead[k][q].v);
@@ -467,8 +483,15 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                     emitRay = true;
                 } while (false);
             }
-            waveAppend(emitShadow, p, w.shadowq, &c->shadowCount[k].v);
-            waveAppend(emitRay, p, w.rayq[(k + 1) & 1], &c->rayCount[k + 1].v);
+            if (sub == 64 && base + 64 < n) {  // a second half follows (the loop cannot leave before it): append then
+                pendP = p;
+                pendShadow = emitShadow;
+                pendRay = emitRay;
+            } else {
+                waveAppend2(pendShadow, pendP, emitShadow, p, w.shadowq, &c->shadowCount[k].v);
+                waveAppend2(pendRay, pendP, emitRay, p, w.rayq[(k + 1) & 1], &c->rayCount[k + 1].v);
+                pendShadow = pendRay = false;
+            }
         }
     }
 }
