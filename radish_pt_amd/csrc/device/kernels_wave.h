@@ -65,17 +65,27 @@ RD_DEV void waveAppend(bool pred, int item, int *queue, int *count) {
     if (pred) queue[base + __popcll(mask & laneMaskLt())] = item;
 }
 
-// The same for the two 64-record halves of a 128-record packet at once: ONE returning atomic (they serialise chip-wide per
+// The same for the 64-record chunks of one k_wf_shade packet at once: ONE returning atomic (they serialise chip-wide per
 // counter at ~12 ns; k_wf_shade's two appends per 64 records were most of its time).
-RD_DEV void waveAppend2(bool pred0, int item0, bool pred1, int item1, int *queue, int *count) {
-    const unsigned long long m0 = __ballot(pred0), m1 = __ballot(pred1);
-    const int n0 = __popcll(m0), total = n0 + __popcll(m1);
+constexpr int kShadeChunks = 4;  // k_wf_shade: 64-record chunks per packet
+constexpr int kShadePacket = 64 * kShadeChunks;
+RD_DEV void waveAppendN(const bool (&pred)[kShadeChunks], const int (&item)[kShadeChunks], int *queue, int *count) {
+    unsigned long long m[kShadeChunks];
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < kShadeChunks; j++) {
+        m[j] = __ballot(pred[j]);
+        total += __popcll(m[j]);
+    }
     if (total == 0) return;
     int base = 0;
     if ((threadIdx.x & 63u) == 0u) base = atomicAdd(count, total);
     base = __shfl(base, 0, 64);
-    if (pred0) queue[base + __popcll(m0 & laneMaskLt())] = item0;
-    if (pred1) queue[base + n0 + __popcll(m1 & laneMaskLt())] = item1;
+#pragma unroll
+    for (int j = 0; j < kShadeChunks; j++) {
+        if (pred[j]) queue[base + __popcll(m[j] & laneMaskLt())] = item[j];
+        base += __popcll(m[j]);
+    }
 }
 
 // Work distribution for the persistent kernels.  Same-address returning atomics serialise chip-wide at ~12 ns each
@@ -85,10 +95,10 @@ RD_DEV void waveAppend2(bool pred0, int item0, bool pred1, int item1, int *queue
 constexpr int kPacket = 128;
 RD_DEV int globalWave() { return int(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
 RD_DEV int gridWaves() { return int(gridDim.x * (blockDim.x >> 6)); }
-RD_DEV int wavePull(int *head) {
+RD_DEV int wavePull(int *head, int packet = kPacket) {
     int base = 0;
-    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(head, kPacket);
-    return __shfl(base, 0, 64) + gridWaves() * kPacket;
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(head, packet);
+    return __shfl(base, 0, 64) + gridWaves() * packet;
 }
 
 // ---- raygen ---------------------------------------------------------------------------------------------------
@@ -375,12 +385,17 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
     for (int q = 0; q < (sorted ? 4 : 1); q++) {
         const int n = sorted ? c->hitCount[k][q].v : c->rayCount[k].v;
         const int *hitq = sorted ? w.hitq[q] : w.rayq[k & 1];
-        static_assert(kPacket == 128, "k_wf_shade appends once per packet of two 64-record halves");
-        int pendP = -1;  // first half of the packet: held until the second half has been shaded, then appended together
-        bool pendShadow = false, pendRay = false;
-        for (int base = globalWave() * kPacket, sub = 0;;) {
-            if (sub == kPacket) {
-                base = wavePull(&c->shadeHead[k][q].v);
+        // queue entries of the packet's chunks, held until its last chunk has been shaded, then appended together
+        int pendP[kShadeChunks];
+        bool pendShadow[kShadeChunks], pendRay[kShadeChunks];
+#pragma unroll
+        for (int j = 0; j < kShadeChunks; j++) {
+            pendP[j] = -1;
+            pendShadow[j] = pendRay[j] = false;
+        }
+        for (int base = globalWave() * kShadePacket, sub = 0;;) {
+            if (sub == kShadePacket) {
+                base = wavePull(&c->shadeHead[k][q].v, kShadePacket);
                 sub = 0;
             }
             if (base + sub >= n) break;
@@ -483,14 +498,21 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                     emitRay = true;
                 } while (false);
             }
-            if (sub == 64 && base + 64 < n) {  // a second half follows (the loop cannot leave before it): append then
-                pendP = p;
-                pendShadow = emitShadow;
-                pendRay = emitRay;
-            } else {
-                waveAppend2(pendShadow, pendP, emitShadow, p, w.shadowq, &c->shadowCount[k].v);
-                waveAppend2(pendRay, pendP, emitRay, p, w.rayq[(k + 1) & 1], &c->rayCount[k + 1].v);
-                pendShadow = pendRay = false;
+            {
+                const int j = (sub >> 6) - 1;  // chunk just shaded (wave-uniform)
+#pragma unroll
+                for (int jj = 0; jj < kShadeChunks; jj++)
+                    if (jj == j) {
+                        pendP[jj] = p;
+                        pendShadow[jj] = emitShadow;
+                        pendRay[jj] = emitRay;
+                    }
+            }
+            if (sub == kShadePacket || base + sub >= n) {  // last chunk of the packet (the loop leaves or pulls next): append
+                waveAppendN(pendShadow, pendP, w.shadowq, &c->shadowCount[k].v);
+                waveAppendN(pendRay, pendP, w.rayq[(k + 1) & 1], &c->rayCount[k + 1].v);
+#pragma unroll
+                for (int jj = 0; jj < kShadeChunks; jj++) pendShadow[jj] = pendRay[jj] = false;
             }
         }
     }
