@@ -26,6 +26,7 @@ extern "C" {
 #define RDH_ERR_UNSUPPORTED (-3) /* a combination that is not built (e.g. a diagnostic entry in a non-diagnostic build) */
 #define RDH_ERR_NO_DEVICE (-4)   /* no usable HIP device — there is NO CPU fallback       */
 #define RDH_ERR_STATE (-5)       /* e.g. rdh_restir_direct before rdh_restir_init         */
+#define RDH_ERR_COMM (-6)        /* RCCL missing or an nccl* call failed (rdh_last_error has ncclGetErrorString's text) */
 
 typedef struct rdh_ctx rdh_ctx;
 
@@ -99,6 +100,8 @@ typedef struct rdh_counters {
                                   G-buffer uses for literal-class rays); for tests            */
 #define RDH_PT_NO_DEFER 128u   /* rdh_gbuffer_render: trace literal-class rays where they are generated (one wave each)
                                   instead of setting them aside for the workgroup-per-ray launch (k_gbuffer_literal)   */
+#define RDH_PT_PARTITION_GBUFFER 512u /* rdh_gbuffer_render on a tile partition: render the records of THIS rank's tiles only
+                                  (complete the planes with rdh_gbuffer_exchange*); default: every rank renders the whole frame */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read            */
@@ -167,6 +170,40 @@ int rdh_restir_direct(rdh_ctx *ctx, float *d_directIllum, int iter, int looper, 
  * float[world][tilesPerRank][tile^2][9]).  Results are bit-identical to the single-GPU frame. */
 int rdh_restir_exchange_pack(rdh_ctx *ctx, float *d_packed);
 int rdh_restir_exchange_unpack(rdh_ctx *ctx, const float *d_gathered);
+/* G-buffer on a tile partition without replicated work: rdh_gbuffer_render(..., RDH_PT_PARTITION_GBUFFER) writes the records of
+ * this rank's tiles (one primary ray per OWN pixel instead of per frame pixel); rdh_gbuffer_exchange_pack gathers them into
+ * d_packed: float[tilesPerRank][tile^2][9] = {albedo.xyz, normal.xyz, motion, depth, primId} (ints as their bits) → all-gather →
+ * rdh_gbuffer_exchange_unpack(d_gathered: float[world][tilesPerRank][tile^2][9]) scatters every rank's records into the
+ * current planes (gb->frameIdx) of this rank's G-buffer: 36 B per pixel of the frame received per rank and frame. */
+int rdh_gbuffer_exchange_pack(rdh_ctx *ctx, const rdh_gbuffer *gb, float *d_packed);
+int rdh_gbuffer_exchange_unpack(rdh_ctx *ctx, const rdh_gbuffer *gb, const float *d_gathered);
+
+/* ---- collectives from C++: RCCL over xGMI (no reference counterpart: the reference is single-device,
+ *      /root/reference/src/preview.cpp:109 cudaGLSetGLDevice(0); frame loop /root/reference/src/main.cpp:163-202) ------------
+ * One process (or host thread) per GPU.  Rank 0 calls rdh_comm_unique_id and hands the 128 bytes (== ncclUniqueId) to the other
+ * ranks by any channel; every rank then calls rdh_comm_init on its context, which creates the communicator (ncclCommInitRank)
+ * and sets the tile partition to (rank, world, current tile size).  RCCL is bound at run time (dlopen of the copy the process
+ * already holds, else librccl.so.1; RADISH_RCCL_LIB overrides) so the library itself links only the HIP runtime.
+ * Every collective below is enqueued on the context's stream and returns without synchronising.
+ *   rdh_allgather_tiles          d_packed float[tilesPerRank][tile^2][3] → ONE ncclAllGather → k_untile → d_frame float[H*W][3]
+ *   rdh_path_trace_gathered      pathTrace for N GPUs with the reference's signature semantics: whole-frame images in and out on
+ *                                every rank (the running mean reads the caller's frame); renders this rank's tiles, then two
+ *                                all-gathers (direct, indirect).  Works with world == 1 (RCCL accepts a single rank).
+ *   rdh_restir_exchange          this rank's pre-spatial reservoirs of the frame just rendered → all-gather → every rank's
+ *                                `last` reservoir buffer holds the whole frame (next frame's temporal reuse): 36 B/px
+ *   rdh_restir_direct_gathered   ReSTIRDirect for N GPUs: whole-frame image in and out, includes rdh_restir_exchange
+ *   rdh_gbuffer_exchange         pack → all-gather → unpack of the G-buffer records (see above)                              */
+int rdh_comm_unique_id(void *id128);
+int rdh_comm_init(rdh_ctx *ctx, const void *id128, int rank, int world);
+int rdh_comm_destroy(rdh_ctx *ctx);
+int rdh_allgather_tiles(rdh_ctx *ctx, const float *d_packed, float *d_frame);
+int rdh_path_trace_gathered(rdh_ctx *ctx, float *d_directFrame, float *d_indirectFrame, int iter, int looper, int maxDepth,
+                            uint32_t flags);
+int rdh_restir_exchange(rdh_ctx *ctx);
+int rdh_restir_direct_gathered(rdh_ctx *ctx, float *d_directFrame, int iter, int looper, const rdh_gbuffer *gb,
+                               const rdh_restir_params *params, uint32_t flags);
+int rdh_gbuffer_exchange(rdh_ctx *ctx, const rdh_gbuffer *gb);
+
 /* Display path (the step after the hot path): replaces copyImageToPBO's four overloads → sendImageToPBO
  * (/root/reference/src/pathtrace.cu:32-147; declared src/pathtrace.h:25-29).  d_pbo: uchar4[width*height] (alpha 0).
  * kind 0: d_image is vec3[w*h], colour = image * scale, tone mapping 0 None / 1 Filmic / 2 ACES (src/common.h:23-25),
@@ -212,6 +249,17 @@ int rdh_restir_read(rdh_ctx *ctx, int which, void *hostOut);
 int rdh_trace_closest(rdh_ctx *ctx, const float *d_rays, int64_t n, rdh_hit *d_hits, uint32_t flags);
 /* d_segments: {x.xyz, y.xyz}[n] -> d_occluded[n] in {0,1}.  DevScene::testOcclusion (src/scene.h:303-334). */
 int rdh_trace_occluded(rdh_ctx *ctx, const float *d_segments, int64_t n, int32_t *d_occluded, uint32_t flags);
+
+/* The ray lists of one frame, for the traversal-only measurements (bench.py roofline.traversal_only, cpu_baseline): runs the
+ * frame `looper` of pathTrace (iter 0, one-lane-per-pixel kernel, scratch images) and appends every DevScene::intersect ray
+ * {origin, direction} to d_closest (float[capClosest][6]) and every DevScene::testOcclusion segment {x, y} to d_any
+ * (float[capAny][6]) — the input layouts of rdh_trace_closest / rdh_trace_occluded.  *nClosest / *nAny are the numbers of rays
+ * the frame traces (rays beyond a capacity are counted, not stored; pass capacities 0 to size the lists).  Blocking. */
+int rdh_dump_rays(rdh_ctx *ctx, int looper, int maxDepth, float *d_closest, int64_t capClosest, float *d_any, int64_t capAny,
+                  int64_t *nClosest, int64_t *nAny);
+/* Contexts that render CONCURRENTLY on one GPU (several frames in flight, each on its own stream): the persistent kernels size
+ * their grid to fill the chip; `share` divides it so that `share` contexts together fill it once.  Default 1. */
+int rdh_set_occupancy_share(rdh_ctx *ctx, int share);
 
 int rdh_counters_reset(rdh_ctx *ctx);
 int rdh_counters_read(rdh_ctx *ctx, rdh_counters *out); /* blocking */

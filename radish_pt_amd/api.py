@@ -33,6 +33,7 @@ RDH_PT_ONE_LANE_PER_PIXEL = 64
 RDH_PT_MEGA_GBUFFER = RDH_PT_ONE_LANE_PER_PIXEL
 RDH_PT_NO_DEFER = 128
 RDH_PT_WG_PER_RAY = 256
+RDH_PT_PARTITION_GBUFFER = 512
 SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12
 
 # Every symbol include/radish_hip.h declares (tests check that the library exports all of them).
@@ -43,6 +44,8 @@ EXPORTS = [
     "rdh_restir_read", "rdh_copy_image_to_pbo", "rdh_denoise_eaw", "rdh_denoise_svgf", "rdh_denoise_modulate",
     "rdh_denoise_add", "rdh_denoise_temporal_accumulate", "rdh_denoise_estimate_variance", "rdh_denoise_filter_variance", "rdh_restir_exchange_pack", "rdh_restir_exchange_unpack", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
     "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps", "rdh_debug_persist_phases",
+    "rdh_gbuffer_exchange_pack", "rdh_gbuffer_exchange_unpack", "rdh_comm_unique_id", "rdh_comm_init", "rdh_comm_destroy",
+    "rdh_dump_rays", "rdh_set_occupancy_share", "rdh_allgather_tiles", "rdh_path_trace_gathered", "rdh_restir_exchange", "rdh_restir_direct_gathered", "rdh_gbuffer_exchange",
 ]
 
 
@@ -137,6 +140,18 @@ def lib():
             "rdh_profile_read": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)], i32),
             "rdh_debug_persist_stamps": ([vp, vp], i32),
             "rdh_debug_persist_phases": ([vp, vp], i32),
+            "rdh_gbuffer_exchange_pack": ([vp, C.POINTER(GBufferC), vp], i32),
+            "rdh_gbuffer_exchange_unpack": ([vp, C.POINTER(GBufferC), vp], i32),
+            "rdh_comm_unique_id": ([vp], i32),
+            "rdh_comm_init": ([vp, vp, i32, i32], i32),
+            "rdh_comm_destroy": ([vp], i32),
+            "rdh_allgather_tiles": ([vp, vp, vp], i32),
+            "rdh_path_trace_gathered": ([vp, vp, vp, i32, i32, i32, u32], i32),
+            "rdh_restir_exchange": ([vp], i32),
+            "rdh_restir_direct_gathered": ([vp, vp, i32, i32, C.POINTER(GBufferC), C.POINTER(RestirParamsC), u32], i32),
+            "rdh_gbuffer_exchange": ([vp, C.POINTER(GBufferC)], i32),
+            "rdh_dump_rays": ([vp, i32, i32, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)], i32),
+            "rdh_set_occupancy_share": ([vp, i32], i32),
         }
         for name, (args, res) in sig.items():
             fn = getattr(l, name)
@@ -168,8 +183,33 @@ class Context:
             raise RadishError(f"rdh_create failed with code {rc} (no usable HIP device?)")
         self.h = h
         self.device = device
+        self.rank, self.world, self.tile = 0, 1, 64
+        self.width = self.height = 0
         if use_torch_stream:
             self.check(lib().rdh_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+
+    # ---- argument checks: the C ABI takes raw device pointers, so a wrongly shaped tensor would be a silent out-of-bounds
+    # device write; every image-like argument is checked here (dtype, device, contiguity, minimum element count) ----
+    def _ptr(self, t, min_elems, what, dtype=None):
+        torch = _torch()
+        dtype = dtype or torch.float32
+        if not isinstance(t, torch.Tensor):
+            raise RadishError(f"{what}: expected a torch tensor, got {type(t).__name__}")
+        if not t.is_cuda or t.device.index != self.device:
+            raise RadishError(f"{what}: tensor is on {t.device}, the context is on cuda:{self.device}")
+        if t.dtype != dtype:
+            raise RadishError(f"{what}: dtype {t.dtype}, expected {dtype}")
+        if not t.is_contiguous():
+            raise RadishError(f"{what}: tensor is not contiguous")
+        if t.numel() < min_elems:
+            raise RadishError(f"{what}: {t.numel()} elements, the call writes/reads {min_elems}")
+        return t.data_ptr()
+
+    def _image_elems(self, gathered=False):
+        """floats of one vec3 image argument: the frame, or this rank's packed tiles on a partition"""
+        if getattr(self, "world", 1) > 1 and not gathered:
+            return self.tiles_per_rank() * self.tile * self.tile * 3
+        return self.width * self.height * 3
 
     def check(self, rc):
         if rc != 0:
@@ -221,6 +261,7 @@ class Context:
 
     def set_partition(self, rank, world, tile=64):
         self.check(lib().rdh_set_partition(self.h, rank, world, tile))
+        self.rank, self.world, self.tile = rank, world, tile
 
     def tiles_per_rank(self):
         n = lib().rdh_tiles_per_rank(self.h)
@@ -229,14 +270,19 @@ class Context:
         return n
 
     def untile(self, gathered, frame):
-        self.check(lib().rdh_untile(self.h, gathered.data_ptr(), frame.data_ptr()))
+        shard = self.tiles_per_rank() * self.tile * self.tile * 3
+        self.check(lib().rdh_untile(self.h, self._ptr(gathered, shard * self.world, "untile: gathered"),
+                                    self._ptr(frame, self.width * self.height * 3, "untile: frame")))
 
     # ---- hot path ----
     def path_trace(self, direct, indirect, iter, looper, max_depth, flags=RDH_PT_PERSISTENT):
-        self.check(lib().rdh_path_trace(self.h, direct.data_ptr(), indirect.data_ptr(), iter, looper, max_depth, flags))
+        n = self._image_elems() if self.width else 0
+        self.check(lib().rdh_path_trace(self.h, self._ptr(direct, n, "pathTrace: directIllum"),
+                                        self._ptr(indirect, n, "pathTrace: indirectIllum"), iter, looper, max_depth, flags))
 
     def path_trace_direct(self, direct, iter, looper, flags=0):
-        self.check(lib().rdh_path_trace_direct(self.h, direct.data_ptr(), iter, looper, flags))
+        n = self._image_elems() if self.width else 0
+        self.check(lib().rdh_path_trace_direct(self.h, self._ptr(direct, n, "pathTraceDirect: directIllum"), iter, looper, flags))
 
     def gbuffer_render(self, gb_c, flags=0):
         self.check(lib().rdh_gbuffer_render(self.h, C.byref(gb_c), flags))
@@ -250,10 +296,20 @@ class Context:
     def restir_direct(self, direct, iter, looper, gb_c, reuse_mask, ris_count=32, num_spatial=5, temporal_clamp=20,
                       faithful_ris=1, flags=0):
         p = RestirParamsC(reuse_mask, ris_count, num_spatial, temporal_clamp, faithful_ris)
-        self.check(lib().rdh_restir_direct(self.h, direct.data_ptr(), iter, looper, C.byref(gb_c), C.byref(p), flags))
+        n = self._image_elems() if self.width else 0
+        self.check(lib().rdh_restir_direct(self.h, self._ptr(direct, n, "ReSTIRDirect: directIllum"), iter, looper, C.byref(gb_c),
+                                           C.byref(p), flags))
 
     def copy_image_to_pbo(self, pbo, image, width, height, kind=0, tone_mapping=0, scale=1.0):
-        self.check(lib().rdh_copy_image_to_pbo(self.h, pbo.data_ptr(), image.data_ptr(), width, height, kind, tone_mapping, scale))
+        torch = _torch()
+        n = width * height
+        if pbo.numel() * pbo.element_size() < 4 * n or not pbo.is_cuda or not pbo.is_contiguous():
+            raise RadishError("copyImageToPBO: PBO must be a contiguous device buffer of 4 bytes per pixel")
+        want = {0: (3 * n, torch.float32), 1: (2 * n, torch.float32), 2: (n, torch.float32), 3: (n, torch.int32)}.get(kind)
+        if want is None:
+            raise RadishError(f"copyImageToPBO: kind {kind}")
+        self.check(lib().rdh_copy_image_to_pbo(self.h, pbo.data_ptr(), self._ptr(image, want[0], "copyImageToPBO: image", want[1]),
+                                               width, height, kind, tone_mapping, scale))
 
     # ---- denoisers (src/denoiser.cu) ----
     @staticmethod
@@ -289,10 +345,61 @@ class Context:
         self.check(lib().rdh_denoise_filter_variance(self.h, var_out.data_ptr(), var_in.data_ptr(), width, height))
 
     def restir_exchange_pack(self, packed):
-        self.check(lib().rdh_restir_exchange_pack(self.h, packed.data_ptr()))
+        shard = self.tiles_per_rank() * self.tile * self.tile * 9
+        self.check(lib().rdh_restir_exchange_pack(self.h, self._ptr(packed, shard, "restir_exchange_pack")))
 
     def restir_exchange_unpack(self, gathered):
-        self.check(lib().rdh_restir_exchange_unpack(self.h, gathered.data_ptr()))
+        shard = self.tiles_per_rank() * self.tile * self.tile * 9
+        self.check(lib().rdh_restir_exchange_unpack(self.h, self._ptr(gathered, shard * self.world, "restir_exchange_unpack")))
+
+    def gbuffer_exchange_pack(self, gb_c, packed):
+        shard = self.tiles_per_rank() * self.tile * self.tile * 9
+        self.check(lib().rdh_gbuffer_exchange_pack(self.h, C.byref(gb_c), self._ptr(packed, shard, "gbuffer_exchange_pack")))
+
+    def gbuffer_exchange_unpack(self, gb_c, gathered):
+        shard = self.tiles_per_rank() * self.tile * self.tile * 9
+        self.check(lib().rdh_gbuffer_exchange_unpack(self.h, C.byref(gb_c), self._ptr(gathered, shard * self.world, "gbuffer_exchange_unpack")))
+
+    # ---- collectives inside the library (RCCL, bound at run time) ----
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes (ncclUniqueId): made on rank 0, handed to every rank's comm_init."""
+        buf = (C.c_uint8 * 128)()
+        rc = lib().rdh_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise RadishError(f"rdh_comm_unique_id failed with code {rc} (RCCL not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128)(*unique_id)
+        self.check(lib().rdh_comm_init(self.h, C.cast(buf, C.c_void_p), rank, world))
+        self.rank, self.world = rank, world
+
+    def comm_destroy(self):
+        self.check(lib().rdh_comm_destroy(self.h))
+
+    def allgather_tiles(self, packed, frame):
+        shard = self.tiles_per_rank() * self.tile * self.tile * 3
+        self.check(lib().rdh_allgather_tiles(self.h, self._ptr(packed, shard, "allgather_tiles: packed"),
+                                             self._ptr(frame, self.width * self.height * 3, "allgather_tiles: frame")))
+
+    def path_trace_gathered(self, direct_frame, indirect_frame, iter, looper, max_depth, flags=RDH_PT_PERSISTENT):
+        n = self.width * self.height * 3
+        self.check(lib().rdh_path_trace_gathered(self.h, self._ptr(direct_frame, n, "path_trace_gathered: direct"),
+                                                 self._ptr(indirect_frame, n, "path_trace_gathered: indirect"), iter, looper,
+                                                 max_depth, flags))
+
+    def restir_exchange(self):
+        self.check(lib().rdh_restir_exchange(self.h))
+
+    def restir_direct_gathered(self, direct_frame, iter, looper, gb_c, reuse_mask, ris_count=32, num_spatial=5, temporal_clamp=20,
+                               faithful_ris=1, flags=0):
+        p = RestirParamsC(reuse_mask, ris_count, num_spatial, temporal_clamp, faithful_ris)
+        self.check(lib().rdh_restir_direct_gathered(self.h, self._ptr(direct_frame, self.width * self.height * 3, "restir_direct_gathered"),
+                                                    iter, looper, C.byref(gb_c), C.byref(p), flags))
+
+    def gbuffer_exchange(self, gb_c):
+        self.check(lib().rdh_gbuffer_exchange(self.h, C.byref(gb_c)))
 
     def restir_read(self, which):
         out = np.zeros(self.width * self.height, dtype=L.RESERVOIR_DTYPE)
@@ -300,10 +407,31 @@ class Context:
         return out
 
     def trace_closest(self, rays, hits, flags=RDH_PT_PERSISTENT):  # flags without RDH_PT_PERSISTENT: one lane per ray
-        self.check(lib().rdh_trace_closest(self.h, rays.data_ptr(), rays.numel() // 6, hits.data_ptr(), flags))
+        n = rays.numel() // 6  # n == 0 still reaches the library (it returns at once)
+        self.check(lib().rdh_trace_closest(self.h, self._ptr(rays, 6 * n, "trace_closest: rays"), n,
+                                           self._ptr(hits, 4 * n, "trace_closest: hits", _torch().int32), flags))
 
     def trace_occluded(self, segments, out, flags=RDH_PT_PERSISTENT):
-        self.check(lib().rdh_trace_occluded(self.h, segments.data_ptr(), segments.numel() // 6, out.data_ptr(), flags))
+        n = segments.numel() // 6
+        self.check(lib().rdh_trace_occluded(self.h, self._ptr(segments, 6 * n, "trace_occluded: segments"), n,
+                                            self._ptr(out, n, "trace_occluded: out", _torch().int32), flags))
+
+    def dump_rays(self, looper, max_depth):
+        """The frame's own ray lists (see rdh_dump_rays): (closest rays float32 [n,6], occlusion segments float32 [m,6]) on the device."""
+        torch = _torch()
+        nc, na = C.c_int64(0), C.c_int64(0)
+        self.check(lib().rdh_dump_rays(self.h, looper, max_depth, None, 0, None, 0, C.byref(nc), C.byref(na)))
+        dev = torch.device("cuda", self.device)
+        closest = torch.zeros(max(nc.value, 1), 6, device=dev)
+        segs = torch.zeros(max(na.value, 1), 6, device=dev)
+        n2, a2 = C.c_int64(0), C.c_int64(0)
+        self.check(lib().rdh_dump_rays(self.h, looper, max_depth, closest.data_ptr(), nc.value, segs.data_ptr(), na.value,
+                                       C.byref(n2), C.byref(a2)))
+        assert (n2.value, a2.value) == (nc.value, na.value)
+        return closest[:nc.value], segs[:na.value]
+
+    def set_occupancy_share(self, share):
+        self.check(lib().rdh_set_occupancy_share(self.h, share))
 
     def counters_reset(self):
         self.check(lib().rdh_counters_reset(self.h))

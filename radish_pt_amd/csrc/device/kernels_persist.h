@@ -813,9 +813,11 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
 // twice the rest of the pass.  The ray's class depends on the camera and the pixel only, so a first tiny kernel lists them;
 // when there are more than kDeferCap (an axis-aligned camera makes a whole pixel row such rays) none is set aside — many
 // one-wave traces in parallel are the better use of the chip then.
-__global__ __launch_bounds__(256) void k_gbuffer_find_literal(DScene s, DCamera cam, PersistCounters *pc) {
+__global__ __launch_bounds__(256) void k_gbuffer_find_literal(DScene s, DCamera cam, PixelMap pm, PersistCounters *pc) {
     const int idx = int(blockIdx.x * blockDim.x + threadIdx.x);
     if (idx >= cam.resx * cam.resy || s.bvhSize == 0) return;
+    // on a tile partition only the rays of this rank's tiles (tile t belongs to rank t % world)
+    if (pm.world > 1 && (((idx / cam.resx) / pm.tile) * pm.tilesX + (idx % cam.resx) / pm.tile) % pm.world != pm.rank) return;
     Ray ray = gbufPrimaryRay(cam, idx % cam.resx, idx / cam.resx);
     if (makeRaySlab(ray).cls != 0) {
         const int at = atomicAdd(&pc->deferCount, 1);

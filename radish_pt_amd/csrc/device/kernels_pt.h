@@ -108,11 +108,29 @@ __global__ __launch_bounds__(256) void k_trace_occluded(DScene s, const float *_
     if (COUNT) flushCounters(s.counters, 0u, valid ? 1u : 0u, 0u, ws);
 }
 
+// Optional ray dump of a frame (rdh_dump_rays): every ray the frame traces is appended to one of two lists, in the layout
+// rdh_trace_closest / rdh_trace_occluded take — {origin, direction} per closest-hit ray, {x, y} per occlusion segment — so the
+// walk-only kernel can be timed, and the CPU traversal baseline run, on exactly the frame's own rays (bench.py
+// roofline.traversal_only).  Rays beyond a list's capacity are counted but not stored.
+struct RayDump {
+    float *closest, *any;            // nullptr: no dump
+    long long capClosest, capAny;
+    unsigned long long *count;       // [0] closest-hit rays, [1] occlusion segments
+};
+RD_DEV void dumpRay(const RayDump &d, int which, v3 a, v3 b) {
+    const unsigned long long at = atomicAdd(&d.count[which], 1ull);
+    float *dst = which ? d.any : d.closest;
+    if ((long long)at < (which ? d.capAny : d.capClosest)) {
+        dst[6 * at] = a.x; dst[6 * at + 1] = a.y; dst[6 * at + 2] = a.z;
+        dst[6 * at + 3] = b.x; dst[6 * at + 4] = b.y; dst[6 * at + 5] = b.z;
+    }
+}
+
 // ---- singleKernelPT (pathtrace.cu:149-291) ----------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool DUMP = false>
 __global__ __launch_bounds__(256) void k_path_trace_mega(DScene s, DCamera cam, PixelMap pm, int looper, int iter,
                                                          int maxDepth, float *__restrict__ directIllum,
-                                                         float *__restrict__ indirectIllum) {
+                                                         float *__restrict__ indirectIllum, RayDump dump = RayDump{}) {
     Pix px = mapWavePixel(pm);  // single-wave workgroups: 64 threads, one 8x8 block each
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
@@ -121,6 +139,7 @@ __global__ __launch_bounds__(256) void k_path_trace_mega(DScene s, DCamera cam, 
         v3 direct = mk3(0.f), indirect = mk3(0.f);
         Sampler rng = makeSeededRandomEngine(looper, px.index, 0, s.sobol);
         Ray ray = cameraSample(cam, px.x, px.y, sample4D(rng));
+        if (DUMP) dumpRay(dump, 0, ray.o, ray.d);
         HitRec h = traceClosest<COUNT>(s, ray, ws);
         nClosest++;
         do {  // `goto WriteRadiance`
@@ -149,6 +168,7 @@ __global__ __launch_bounds__(256) void k_path_trace_mega(DScene s, DCamera cam, 
                     if (s.lightSamplerLength != 0) {  // sampleDirectLight (scene.h:419-456)
                         LightPick lp = pickLightPoint(s, isec.pos, r4);
                         nAny++;
+                        if (DUMP) dumpRay(dump, 1, isec.pos, lp.sampled);
                         bool occ = traceOccluded<COUNT>(s, isec.pos, lp.sampled, ws);
                         if (!occ) lightPdf = lightPdfUnoccluded(s, isec.pos, lp, radiance, wi);
                     }
@@ -169,6 +189,7 @@ __global__ __launch_bounds__(256) void k_path_trace_mega(DScene s, DCamera cam, 
                 throughput = throughput * (sample.bsdf / sample.pdf * (deltaSample ? 1.f : absDot(isec.norm, sample.dir)));
                 ray = makeOffsetedRay(isec.pos, sample.dir);
                 v3 curPos = isec.pos;
+                if (DUMP) dumpRay(dump, 0, ray.o, ray.d);
                 h = traceClosest<COUNT>(s, ray, ws);
                 nClosest++;
                 if (h.prim == -1) {  // :232-247
@@ -335,6 +356,48 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float *__restrict__ fr
     Pix px = mapPixel(q, block, lane);
     if (!px.valid) return;
     for (int c = 0; c < channels; c++) packed[(long long)channels * px.out + c] = frame[(long long)channels * px.index + c];
+}
+
+// ---- G-buffer exchange on a tile partition -------------------------------------------------------------------------------
+// Each rank renders the G-buffer records of ITS tiles (frame layout); k_gbuf_pack gathers them into one 9-float record per
+// pixel of the rank's packed tile buffer — albedo.xyz, normal.xyz, motion, depth, primId (ints carried as their bits) — the
+// send side of one all-gather; k_gbuf_unpack scatters the gathered records of every rank into the frame-layout planes, so
+// that every rank holds the whole frame's G-buffer (ReSTIR's temporal lookup follows motion vectors to arbitrary pixels).
+__global__ __launch_bounds__(256) void k_gbuf_pack(const float *__restrict__ albedo, const float *__restrict__ normal,
+                                                   const int *__restrict__ motion, const float *__restrict__ depth,
+                                                   const int *__restrict__ primId, float *__restrict__ packed, PixelMap pm) {
+    unsigned lane = threadIdx.x & 63u;
+    unsigned block = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (block >= (unsigned)pm.numBlocks) return;
+    PixelMap q = pm;
+    q.packed = 1;
+    Pix px = mapPixel(q, block, lane);
+    if (!px.valid) return;
+    float *o = packed + 9ll * px.out;
+    const long long i = px.index;
+    o[0] = albedo[3 * i]; o[1] = albedo[3 * i + 1]; o[2] = albedo[3 * i + 2];
+    o[3] = normal[3 * i]; o[4] = normal[3 * i + 1]; o[5] = normal[3 * i + 2];
+    o[6] = __int_as_float(motion[i]);
+    o[7] = depth[i];
+    o[8] = __int_as_float(primId[i]);
+}
+__global__ __launch_bounds__(256) void k_gbuf_unpack(const float *__restrict__ gathered, float *__restrict__ albedo,
+                                                     float *__restrict__ normal, int *__restrict__ motion,
+                                                     float *__restrict__ depth, int *__restrict__ primId, int W, int H, int tile,
+                                                     int tilesX, int world, int tilesPerRank) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)W * H) return;
+    int x = int(i % W), y = int(i / W);
+    int tx = x / tile, ty = y / tile;
+    int tileId = ty * tilesX + tx;
+    int rank = tileId % world, localTile = tileId / world;
+    long long src = ((long long)rank * tilesPerRank + localTile) * (long long)(tile * tile) + (y - ty * tile) * tile + (x - tx * tile);
+    const float *r = gathered + 9ll * src;
+    albedo[3 * i] = r[0]; albedo[3 * i + 1] = r[1]; albedo[3 * i + 2] = r[2];
+    normal[3 * i] = r[3]; normal[3 * i + 1] = r[4]; normal[3 * i + 2] = r[5];
+    motion[i] = __float_as_int(r[6]);
+    depth[i] = r[7];
+    primId[i] = __float_as_int(r[8]);
 }
 
 // This rank's tiles grown by one 8-pixel block on every side (>= the 5-pixel radius of ReSTIR's spatial reuse,

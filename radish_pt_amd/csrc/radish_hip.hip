@@ -7,6 +7,7 @@
 #include "radish_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -64,6 +65,8 @@ struct rdh_ctx {
 
     // partition
     int rank = 0, world = 1, tile = 64;
+    int share = 1;  // contexts rendering concurrently on this GPU: persistent grids are divided by it (rdh_set_occupancy_share)
+    bool forcePacked = false;  // render into packed tile buffers even with one rank (the *_gathered entries)
 
     // ReSTIR buffers (restir.cu:4-7)
     float *resvCur = nullptr, *resvLast = nullptr, *resvTemp = nullptr;
@@ -74,6 +77,13 @@ struct rdh_ctx {
     // per-launch timing of the dominant (traversal) kernel: ring of hipEvent pairs (RDH_PT_PROFILE)
     std::vector<hipEvent_t> profEvents;
     size_t profUsed = 0;
+
+    // RCCL communicator of this rank (rdh_comm_init) and the staging buffers of the collectives: this rank's packed tiles
+    // (send side) and the gathered tiles of every rank (receive side), grown on demand
+    void *comm = nullptr;
+    float *commSend[2] = {nullptr, nullptr};
+    float *commRecv = nullptr;
+    size_t commSendFloats[2] = {0, 0}, commRecvFloats = 0;
 
     // wavefront workspace
     WaveWorkspace wf{};
@@ -158,7 +168,7 @@ PixelMap makePixelMap(const rdh_ctx *c) {
     pm.rank = c->rank;
     pm.world = c->world;
     pm.tilesPerRank = (pm.numTiles + pm.world - 1) / pm.world;
-    pm.packed = c->world > 1 ? 1 : 0;
+    pm.packed = (c->world > 1 || c->forcePacked) ? 1 : 0;
     int bpe = pm.tile / 8;
     pm.numBlocks = pm.tilesPerRank * bpe * bpe;
     return pm;
@@ -301,8 +311,14 @@ int rdh_create(rdh_ctx **out, int device) {
         delete c;
         return RDH_ERR_NO_DEVICE;
     }
-    hipMemset(c->dCounters, 0, sizeof(Counters));
     c->stream = c->ownStream;
+    // cleared on the context's own (non-blocking) stream: a null-stream memset is not ordered against it
+    if (hipMemsetAsync(c->dCounters, 0, sizeof(Counters), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->dPersist, 0, sizeof(PersistCounters), c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        delete c;
+        return RDH_ERR_NO_DEVICE;
+    }
     *out = c;
     return RDH_OK;
 }
@@ -322,6 +338,7 @@ void rdh_destroy(rdh_ctx *c) {
     hipSetDevice(c->device);
     rdh_scene_free(c);
     rdh_restir_free(c);
+    rdh_comm_destroy(c);
     for (void *p : c->wfAllocs) hipFree(p);
     for (hipEvent_t e : c->profEvents) hipEventDestroy(e);
     if (c->dCounters) hipFree(c->dCounters);
@@ -348,7 +365,17 @@ const char *rdh_last_error(const rdh_ctx *c) { return c ? c->err.c_str() : "null
 
 int rdh_set_stream(rdh_ctx *c, void *s) {
     if (!c) return RDH_ERR_ARGS;
-    c->stream = static_cast<hipStream_t>(s);  // NULL is HIP's default (null) stream, which is what torch uses by default
+    hipStream_t ns = static_cast<hipStream_t>(s);  // NULL is HIP's default (null) stream, which is what torch uses by default
+    if (ns != c->stream) {
+        // The persistent kernels' workspace (block reservation counter, cost / order double buffers, schedule events) and the
+        // fork/join with the side stream assume that every launch of a context is ordered on ONE stream: drain the old one
+        // and restart the block-order sequence before launches move to the new one.
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->sideStream) HIP_TRY(c, hipStreamSynchronize(c->sideStream));
+        c->orderValid = false;
+        c->stream = ns;
+    }
     return RDH_OK;
 }
 
@@ -559,7 +586,9 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
             if (perCU > 1) perCU -= 0;  // SGPR-heavy kernels: the API can over-report by one (MI355X_MICROARCH.md); VGPR-bound here
             c->persistGrid = (unsigned)(perCU * cus);
         }
-        unsigned grid = groups < c->persistGrid ? groups : c->persistGrid;
+        unsigned residentGrid = c->persistGrid / (unsigned)c->share;
+        if (residentGrid < 8u) residentGrid = 8u;
+        unsigned grid = groups < residentGrid ? groups : residentGrid;
         // longest-paths-first schedule from the previous launch's per-block costs (same partition and resolution only)
         if (c->costBlocks != pm.numBlocks) {
             HIP_TRY(c, hipStreamSynchronize(c->sideStream));
@@ -650,10 +679,13 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
     if (gb->width != c->cam.resx || gb->height != c->cam.resy)
         return fail(c, RDH_ERR_ARGS, "G-buffer %dx%d does not match camera %dx%d", gb->width, gb->height, c->cam.resx, c->cam.resy);
     HIP_TRY(c, hipSetDevice(c->device));
-    // The G-buffer is always the WHOLE frame, on every rank: ReSTIR's temporal lookup follows motion vectors to
-    // arbitrary pixels of the previous frame and its spatial lookup crosses tile borders.
+    // ReSTIR needs the WHOLE frame's G-buffer on every rank: its temporal lookup follows motion vectors to arbitrary pixels
+    // of the previous frame and its spatial lookup crosses tile borders.  Default on a partition: every rank renders the
+    // whole frame (no exchange).  RDH_PT_PARTITION_GBUFFER: this rank renders the records of ITS tiles only (frame layout),
+    // and rdh_gbuffer_exchange[_pack/_unpack] completes the planes with one all-gather of 36 B per pixel.
     PixelMap pm = makePixelMap(c);
-    if (c->world > 1) {
+    pm.packed = 0;  // G-buffer planes are always in frame layout
+    if (c->world > 1 && !(flags & RDH_PT_PARTITION_GBUFFER)) {
         pm.rank = 0;
         pm.world = 1;
         pm.tilesPerRank = pm.numTiles;
@@ -689,7 +721,7 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
     const bool count = (flags & RDH_PT_COUNT) != 0;
     if (defer) {
         const unsigned pixels = (unsigned)(c->cam.resx * c->cam.resy);
-        hipLaunchKernelGGL(k_gbuffer_find_literal, dim3((pixels + 255u) / 256u), dim3(256), 0, c->stream, c->ds, c->cam, c->dPersist);
+        hipLaunchKernelGGL(k_gbuffer_find_literal, dim3((pixels + 255u) / 256u), dim3(256), 0, c->stream, c->ds, c->cam, pm, c->dPersist);
         HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evFork, 0));
         if (count)
@@ -834,6 +866,249 @@ int rdh_restir_read(rdh_ctx *c, int which, void *hostOut) {
     return RDH_OK;
 }
 
+// ---- collectives: RCCL over xGMI, called from C++ (no reference counterpart) -----------------------
+// One process per GPU: every rank creates its context, rank 0 makes a 128-byte id (rdh_comm_unique_id) and hands it to the
+// others by whatever channel the host has (the Python harness broadcasts it over torch.distributed's store, a C++ host can
+// use a file or MPI), every rank calls rdh_comm_init.  RCCL is bound at run time (dlopen), not at link time, so that the
+// library loads — and every single-GPU entry point works — on a machine without RCCL, and so that inside a PyTorch process
+// the communicator lives in the RCCL copy that process already holds.  Data path: ONE ncclAllGather per image (or per
+// reservoir / G-buffer set) per frame on the context's stream, then a local un-tile kernel.  xGMI is point-to-point (7 links
+// per GPU), so the gather's per-peer shards travel on different links concurrently; bytes per rank are in DESIGN §8.
+struct Id128 { char internal[128]; };  // == ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value
+extern "C++" {
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool tried = false;
+};
+RcclApi g_rccl;
+constexpr int kNcclFloat = 7;  // ncclFloat32 (rccl.h ncclDataType_t)
+
+const char *rcclLoad() {
+    if (g_rccl.AllGather) return nullptr;
+    if (g_rccl.tried) return "RCCL could not be loaded";
+    g_rccl.tried = true;
+    void *h = nullptr;
+    // 1. a copy this process already holds (PyTorch's: same HIP runtime as the streams we are given); 2. ROCm's
+    const char *env = getenv("RADISH_RCCL_LIB");
+    if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    if (!h && dlsym(RTLD_DEFAULT, "ncclAllGather")) h = RTLD_DEFAULT;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (int k = 0; !h && k < 2; k++) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    for (int k = 0; !h && k < 2; k++) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+    if (!h) return "librccl.so not found (set RADISH_RCCL_LIB)";
+    g_rccl.handle = h;
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    auto ag = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(h, "ncclAllGather"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !ag) return "librccl.so lacks the nccl* entry points";
+    g_rccl.AllGather = ag;
+    return nullptr;
+}
+
+int rcclFail(rdh_ctx *c, int r, const char *what) {
+    return fail(c, RDH_ERR_COMM, "RCCL error: %s: %s (%d)", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?", r);
+}
+
+int commEnsure(rdh_ctx *c, float **buf, size_t *have, size_t floats) {
+    if (*have >= floats) return RDH_OK;
+    if (*buf) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(*buf);
+        *buf = nullptr;
+        *have = 0;
+    }
+    HIP_TRY(c, hipMalloc((void **)buf, floats * sizeof(float)));
+    *have = floats;
+    return RDH_OK;
+}
+
+// send: this rank's packed tiles, `channels` floats per pixel -> c->commRecv: the packed tiles of every rank, rank-major
+int allGatherPacked(rdh_ctx *c, const float *d_send, int channels, const PixelMap &pm) {
+    if (!c->comm) return fail(c, RDH_ERR_STATE, "no communicator: call rdh_comm_init first");
+    const size_t shard = (size_t)pm.tilesPerRank * pm.tile * pm.tile * channels;
+    int rc = commEnsure(c, &c->commRecv, &c->commRecvFloats, shard * (size_t)pm.world);
+    if (rc) return rc;
+    int r = g_rccl.AllGather(d_send, c->commRecv, shard, kNcclFloat, c->comm, c->stream);
+    if (r != 0) return rcclFail(c, r, "ncclAllGather");
+    return RDH_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int rdh_comm_unique_id(void *id128) {
+    if (!id128) return RDH_ERR_ARGS;
+    if (rcclLoad()) return RDH_ERR_COMM;
+    return g_rccl.GetUniqueId(id128) == 0 ? RDH_OK : RDH_ERR_COMM;
+}
+
+int rdh_comm_init(rdh_ctx *c, const void *id128, int rank, int world) {
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return c ? fail(c, RDH_ERR_ARGS, "rdh_comm_init(rank=%d, world=%d)", rank, world) : RDH_ERR_ARGS;
+    const char *why = rcclLoad();
+    if (why) return fail(c, RDH_ERR_COMM, "%s", why);
+    HIP_TRY(c, hipSetDevice(c->device));
+    rdh_comm_destroy(c);
+    Id128 id;
+    memcpy(&id, id128, sizeof(id));
+    void *comm = nullptr;
+    int r = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (r != 0) return rcclFail(c, r, "ncclCommInitRank");
+    c->comm = comm;
+    return rdh_set_partition(c, rank, world, c->tile);
+}
+
+int rdh_comm_destroy(rdh_ctx *c) {
+    if (!c) return RDH_ERR_ARGS;
+    hipSetDevice(c->device);
+    if (c->comm) {
+        hipStreamSynchronize(c->stream);
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    for (int k = 0; k < 2; k++) {
+        if (c->commSend[k]) hipFree(c->commSend[k]);
+        c->commSend[k] = nullptr;
+        c->commSendFloats[k] = 0;
+    }
+    if (c->commRecv) hipFree(c->commRecv);
+    c->commRecv = nullptr;
+    c->commRecvFloats = 0;
+    return RDH_OK;
+}
+
+int rdh_allgather_tiles(rdh_ctx *c, const float *d_packed, float *d_frame) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_packed || !d_frame) return fail(c, RDH_ERR_ARGS, "rdh_allgather_tiles: null buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    PixelMap pm = makePixelMap(c);
+    if ((rc = allGatherPacked(c, d_packed, 3, pm))) return rc;
+    return rdh_untile(c, c->commRecv, d_frame);
+}
+
+extern "C++" {
+namespace {
+// frame-layout image -> this rank's packed tiles in commSend[k] (the running mean of pathtrace.cu:287-290 reads the caller's
+// image, so the packed render must start from it)
+int packFrame(rdh_ctx *c, const float *d_frame, int k, int channels, const PixelMap &pm) {
+    const size_t shard = (size_t)pm.tilesPerRank * pm.tile * pm.tile * channels;
+    int rc = commEnsure(c, &c->commSend[k], &c->commSendFloats[k], shard);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)(pm.numBlocks + 3) / 4), dim3(256), 0, c->stream, d_frame, c->commSend[k], pm, channels);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+}  // namespace
+}
+
+int rdh_path_trace_gathered(rdh_ctx *c, float *d_directFrame, float *d_indirectFrame, int iter, int looper, int maxDepth,
+                            uint32_t flags) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_directFrame || !d_indirectFrame) return fail(c, RDH_ERR_ARGS, "rdh_path_trace_gathered: null image");
+    if (!c->comm) return fail(c, RDH_ERR_STATE, "no communicator: call rdh_comm_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->forcePacked = true;  // one rank: still render into packed tiles, so that the same path runs at every world size
+    PixelMap pm = makePixelMap(c);
+    if (!(rc = packFrame(c, d_directFrame, 0, 3, pm)) && !(rc = packFrame(c, d_indirectFrame, 1, 3, pm)))
+        rc = rdh_path_trace(c, c->commSend[0], c->commSend[1], iter, looper, maxDepth, flags);
+    c->forcePacked = false;
+    if (rc) return rc;
+    if ((rc = allGatherPacked(c, c->commSend[0], 3, pm))) return rc;
+    if ((rc = rdh_untile(c, c->commRecv, d_directFrame))) return rc;
+    if ((rc = allGatherPacked(c, c->commSend[1], 3, pm))) return rc;
+    return rdh_untile(c, c->commRecv, d_indirectFrame);
+}
+
+int rdh_restir_exchange(rdh_ctx *c) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!c->resvLast) return fail(c, RDH_ERR_STATE, "ReSTIR not initialised");
+    HIP_TRY(c, hipSetDevice(c->device));
+    PixelMap pm = makePixelMap(c);
+    pm.packed = 1;
+    if ((rc = packFrame(c, c->resvLast, 0, 9, pm))) return rc;
+    if ((rc = allGatherPacked(c, c->commSend[0], 9, pm))) return rc;
+    return rdh_restir_exchange_unpack(c, c->commRecv);
+}
+
+int rdh_restir_direct_gathered(rdh_ctx *c, float *d_directFrame, int iter, int looper, const rdh_gbuffer *gb,
+                               const rdh_restir_params *p, uint32_t flags) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_directFrame) return fail(c, RDH_ERR_ARGS, "rdh_restir_direct_gathered: null image");
+    if (!c->comm) return fail(c, RDH_ERR_STATE, "no communicator: call rdh_comm_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->forcePacked = true;
+    PixelMap pm = makePixelMap(c);
+    if (!(rc = packFrame(c, d_directFrame, 1, 3, pm))) rc = rdh_restir_direct(c, c->commSend[1], iter, looper, gb, p, flags);
+    c->forcePacked = false;
+    if (rc) return rc;
+    if ((rc = allGatherPacked(c, c->commSend[1], 3, pm))) return rc;
+    if ((rc = rdh_untile(c, c->commRecv, d_directFrame))) return rc;
+    return rdh_restir_exchange(c);  // next frame's temporal reuse reads the whole frame's reservoirs
+}
+
+extern "C++" {
+namespace {
+int gbufCheck(rdh_ctx *c, const rdh_gbuffer *gb, const char *what) {
+    if (!gb || !gb->albedo || !gb->motion || (gb->frameIdx & ~1)) return fail(c, RDH_ERR_ARGS, "%s: bad G-buffer", what);
+    for (int k = 0; k < 2; k++)
+        if (!gb->normal[k] || !gb->depth[k] || !gb->primId[k]) return fail(c, RDH_ERR_ARGS, "%s: null plane", what);
+    if (gb->width != c->cam.resx || gb->height != c->cam.resy) return fail(c, RDH_ERR_ARGS, "%s: G-buffer size does not match the camera", what);
+    return RDH_OK;
+}
+}  // namespace
+}
+
+int rdh_gbuffer_exchange_pack(rdh_ctx *c, const rdh_gbuffer *gb, float *d_packed) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_packed) return fail(c, RDH_ERR_ARGS, "rdh_gbuffer_exchange_pack: null buffer");
+    if ((rc = gbufCheck(c, gb, "rdh_gbuffer_exchange_pack"))) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    PixelMap pm = makePixelMap(c);
+    const int f = gb->frameIdx;
+    hipLaunchKernelGGL(k_gbuf_pack, dim3((unsigned)(pm.numBlocks + 3) / 4), dim3(256), 0, c->stream, gb->albedo, gb->normal[f], gb->motion,
+                       gb->depth[f], gb->primId[f], d_packed, pm);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_gbuffer_exchange_unpack(rdh_ctx *c, const rdh_gbuffer *gb, const float *d_gathered) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!d_gathered) return fail(c, RDH_ERR_ARGS, "rdh_gbuffer_exchange_unpack: null buffer");
+    if ((rc = gbufCheck(c, gb, "rdh_gbuffer_exchange_unpack"))) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    PixelMap pm = makePixelMap(c);
+    const int f = gb->frameIdx;
+    const long long total = (long long)pm.W * pm.H;
+    hipLaunchKernelGGL(k_gbuf_unpack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_gathered, gb->albedo, gb->normal[f],
+                       gb->motion, gb->depth[f], gb->primId[f], pm.W, pm.H, pm.tile, pm.tilesX, pm.world, pm.tilesPerRank);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
+int rdh_gbuffer_exchange(rdh_ctx *c, const rdh_gbuffer *gb) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!c->comm) return fail(c, RDH_ERR_STATE, "no communicator: call rdh_comm_init first");
+    PixelMap pm = makePixelMap(c);
+    const size_t shard = (size_t)pm.tilesPerRank * pm.tile * pm.tile * 9;
+    if ((rc = commEnsure(c, &c->commSend[0], &c->commSendFloats[0], shard))) return rc;
+    if ((rc = rdh_gbuffer_exchange_pack(c, gb, c->commSend[0]))) return rc;
+    if ((rc = allGatherPacked(c, c->commSend[0], 9, pm))) return rc;
+    return rdh_gbuffer_exchange_unpack(c, gb, c->commRecv);
+}
+
 // RDH_PT_PERSISTENT on the ray-batch entries: the walk-only lane-refill kernel (device/kernels_walk.h); d_hits xor d_occ
 extern "C++" {
 static int walkPersistent(rdh_ctx *c, const float *d_rays, int64_t n, int4 *d_hits, int *d_occ, uint32_t flags, const char *what) {
@@ -902,6 +1177,47 @@ int rdh_trace_occluded(rdh_ctx *c, const float *d_seg, int64_t n, int32_t *d_occ
     else
         hipLaunchKernelGGL(k_trace_occluded<false>, dim3(grid), dim3(256), 0, c->stream, c->ds, d_seg, (long long)n, d_occ);
     return timeEnd(c, "trace_occluded");
+}
+
+int rdh_dump_rays(rdh_ctx *c, int looper, int maxDepth, float *d_closest, int64_t capClosest, float *d_any, int64_t capAny,
+                  int64_t *nClosest, int64_t *nAny) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!nClosest || !nAny || capClosest < 0 || capAny < 0 || (capClosest > 0 && !d_closest) || (capAny > 0 && !d_any) || looper < 0 ||
+        looper >= 10000 || maxDepth < 0 || 4 + 7 * maxDepth > 200)
+        return fail(c, RDH_ERR_ARGS, "rdh_dump_rays: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    PixelMap pm = makePixelMap(c);
+    // scratch images (the frame's pixels are not wanted) + the two list counters
+    float *img = nullptr;
+    unsigned long long *cnt = nullptr;
+    const size_t px = (size_t)(pm.packed ? (long long)pm.tilesPerRank * pm.tile * pm.tile : (long long)pm.W * pm.H);
+    HIP_TRY(c, hipMalloc((void **)&img, px * 6 * sizeof(float)));
+    if (hipMalloc((void **)&cnt, 16) != hipSuccess) {
+        hipFree(img);
+        return fail(c, RDH_ERR_ARGS, "rdh_dump_rays: out of device memory");
+    }
+    hipMemsetAsync(cnt, 0, 16, c->stream);
+    hipMemsetAsync(img, 0, px * 6 * sizeof(float), c->stream);
+    RayDump d{d_closest, d_any, (long long)capClosest, (long long)capAny, cnt};
+    hipLaunchKernelGGL((k_path_trace_mega<false, true>), dim3(gridBlocks(pm)), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, 0,
+                       maxDepth, img, img + px * 3, d);
+    unsigned long long h[2] = {0, 0};
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(h, cnt, 16, hipMemcpyDeviceToHost);
+    hipFree(img);
+    hipFree(cnt);
+    if (e != hipSuccess) return fail(c, (int)e, "HIP error: rdh_dump_rays: %s", hipGetErrorString(e));
+    *nClosest = (int64_t)h[0];
+    *nAny = (int64_t)h[1];
+    return RDH_OK;
+}
+
+int rdh_set_occupancy_share(rdh_ctx *c, int share) {
+    if (!c || share < 1 || share > 64) return c ? fail(c, RDH_ERR_ARGS, "rdh_set_occupancy_share(%d)", share) : RDH_ERR_ARGS;
+    if (share != c->share) c->orderValid = false;
+    c->share = share;
+    return RDH_OK;
 }
 
 int rdh_counters_reset(rdh_ctx *c) {

@@ -7,9 +7,18 @@
 //   scene.cpp     (DevScene::create/destroy)                              /root/reference/src/scene.cpp:461-574
 // keeping the declarations in pathtrace.h / restir.h / gBuffer.h / scene.h untouched, so main.cpp and scene.cpp call
 // exactly what they call today.  It needs only what those translation units already include (glm, the reference's
-// own Scene / Camera / GBuffer / Settings / State definitions).  It is not compiled in this repository: glm and the
-// reference's headers are not available in the build image; the Python mirror radish_pt_amd/api.py is
-// the host side that is exercised by the tests.
+// own Scene / Camera / GBuffer / Settings / State definitions).  glm and the reference's headers are not available in the
+// build image, so it cannot be LINKED into Radish here; tests/test_shim_compiles.py compiles it
+// (-fsyntax-only, -Wall -Werror) against a minimal local set of the declarations it touches (tests/shim/), so that a typo
+// cannot ship, and the Python mirror radish_pt_amd/api.py is the host side the GPU tests exercise.
+//
+// Macros:  RADISH_SHIM_NO_REFERENCE_HEADERS  the including file has already declared glm / Camera / GBuffer / Scene /
+//                                            Settings / State (skip the reference's #includes)
+//          RADISH_SHIM_HELPERS_ONLY          only namespace radish_shim (no free functions)
+//          RADISH_SHIM_WITH_DENOISER         also the bodies of denoiser.h's classes
+//          RADISH_SHIM_MULTI_GPU             pathTrace / ReSTIRDirect / GBuffer::render run on a tile partition over RCCL:
+//                                            call radish_shim::commInit(id, rank, world) once per process (one process per
+//                                            GPU); every rank then gets the whole frame, exactly as the single-GPU calls do
 //
 // Error behaviour reproduces checkCUDAError (src/cudaUtil.h:16-34): print `HIP error (file:line): msg: text` and exit.
 #pragma once
@@ -75,6 +84,15 @@ inline void devSceneCreate(const SceneT &scene, const uint32_t *sobol10kx200) {
 }
 inline void devSceneDestroy() { RADISH_CHECK(rdh_scene_free(ctx()), "DevScene::destroy"); }
 
+// Multi-GPU (no reference counterpart: the reference is single-device, src/preview.cpp:109): one process per GPU.
+// Rank 0 fills id128 with commUniqueId and hands it to the other ranks (file, socket, MPI ...); every rank calls commInit
+// after DevScene::create.  With RADISH_SHIM_MULTI_GPU the free functions below then render this rank's tiles and gather.
+inline void commUniqueId(void *id128) { RADISH_CHECK(rdh_comm_unique_id(id128), "rdh_comm_unique_id"); }
+inline void commInit(const void *id128, int rank, int world, int device = -1) {
+    if (!ctx()) RADISH_CHECK(rdh_create(&ctx(), device < 0 ? rank : device), "rdh_create");
+    RADISH_CHECK(rdh_comm_init(ctx(), id128, rank, world), "rdh_comm_init");
+}
+
 template <typename GBufferT>
 inline rdh_gbuffer toC(const GBufferT &g) {
     static_assert(sizeof(GBufferT) == sizeof(rdh_gbuffer), "GBuffer layout (src/gBuffer.h:42-57)");
@@ -85,7 +103,7 @@ inline rdh_gbuffer toC(const GBufferT &g) {
 
 }  // namespace radish_shim
 
-#ifndef RADISH_SHIM_NO_REFERENCE_HEADERS
+#ifndef RADISH_SHIM_HELPERS_ONLY
 // ---- the reference's free functions, same signatures (src/pathtrace.h:19-23, src/restir.h:103-106) -----------------
 inline void pathTraceInit() { RADISH_CHECK(rdh_synchronize(radish_shim::ctx()), "pathTraceInit"); }
 inline void pathTraceFree() {}
@@ -93,9 +111,15 @@ inline void pathTraceFree() {}
 inline void pathTrace(glm::vec3 *directIllum, glm::vec3 *indirectIllum, int iter) {
     rdh_ctx *c = radish_shim::ctx();
     RADISH_CHECK(rdh_set_camera(c, &State::scene->camera), "pathTrace");
+#ifdef RADISH_SHIM_MULTI_GPU
+    RADISH_CHECK(rdh_path_trace_gathered(c, reinterpret_cast<float *>(directIllum), reinterpret_cast<float *>(indirectIllum), iter,
+                                         State::looper, Settings::traceDepth, RDH_PT_PERSISTENT),
+                 "pathTrace");
+#else
     RADISH_CHECK(rdh_path_trace(c, reinterpret_cast<float *>(directIllum), reinterpret_cast<float *>(indirectIllum), iter,
                                 State::looper, Settings::traceDepth, RDH_PT_PERSISTENT),
                  "pathTrace");
+#endif
     RADISH_CHECK(rdh_synchronize(c), "pathTrace");
     float ms = 0.f;
     if (rdh_last_kernel_ms(c, &ms) == RDH_OK) std::printf("PT runtime%.3f ms\n", ms);  // src/pathtrace.cu:374
@@ -122,7 +146,11 @@ inline void ReSTIRDirect(glm::vec3 *directIllum, int iter, const GBuffer &gBuffe
     rdh_gbuffer g = radish_shim::toC(gBuffer);
     rdh_restir_params p{Settings::reservoirReuse, 32, 5, 20, 1};  // RESERVOIR_SIZE, restir.cu:87, :168, restir.h:21
     RADISH_CHECK(rdh_set_camera(c, &State::scene->camera), "ReSTIR Direct");
+#ifdef RADISH_SHIM_MULTI_GPU
+    RADISH_CHECK(rdh_restir_direct_gathered(c, reinterpret_cast<float *>(directIllum), iter, State::looper, &g, &p, 0), "ReSTIR Direct");
+#else
     RADISH_CHECK(rdh_restir_direct(c, reinterpret_cast<float *>(directIllum), iter, State::looper, &g, &p, 0), "ReSTIR Direct");
+#endif
     RADISH_CHECK(rdh_synchronize(c), "ReSTIR Direct");
     State::looper = (State::looper + 1) % 10000;
 }
@@ -146,7 +174,12 @@ inline void GBuffer::render(DevScene *, const Camera &cam) {
     rdh_ctx *c = radish_shim::ctx();
     rdh_gbuffer g = radish_shim::toC(*this);
     RADISH_CHECK(rdh_set_camera(c, &cam), "renderGBuffer");
+#ifdef RADISH_SHIM_MULTI_GPU  // this rank's tiles only, then one all-gather of 36 B per pixel
+    RADISH_CHECK(rdh_gbuffer_render(c, &g, RDH_PT_PARTITION_GBUFFER), "renderGBuffer");
+    RADISH_CHECK(rdh_gbuffer_exchange(c, &g), "renderGBuffer");
+#else
     RADISH_CHECK(rdh_gbuffer_render(c, &g, 0), "renderGBuffer");
+#endif
     RADISH_CHECK(rdh_synchronize(c), "renderGBuffer");
     float ms = 0.f;
     if (rdh_last_kernel_ms(c, &ms) == RDH_OK) std::printf("GBuffer runtime%.3f ms\n", ms);  // src/gBuffer.cu:98
@@ -157,9 +190,14 @@ namespace radish_shim {
 template <typename T>
 inline T *devAlloc(size_t n) {  // cudaMalloc<T> (src/cudaUtil.h)
     void *p = nullptr;
-    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) check(RDH_ERR_NO_DEVICE, "hipMalloc", __FILE__, __LINE__);
-    hipMemset(p, 0, n * sizeof(T));
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess || hipMemset(p, 0, n * sizeof(T)) != hipSuccess)
+        check(RDH_ERR_NO_DEVICE, "hipMalloc", __FILE__, __LINE__);
     return static_cast<T *>(p);
+}
+template <typename T>
+inline void devFree(T *&p) {  // cudaSafeFree (src/cudaUtil.h)
+    if (p && hipFree(p) != hipSuccess) check(RDH_ERR_NO_DEVICE, "hipFree", __FILE__, __LINE__);
+    p = nullptr;
 }
 inline float *f(glm::vec3 *p) { return reinterpret_cast<float *>(p); }
 }  // namespace radish_shim
@@ -190,7 +228,7 @@ inline void LeveledEAWFilter::create(int width, int height, int level) {  // :41
     waveletFilter = EAWaveletFilter(width, height, 64.f, .2f, 1.f);
     tmpImg = radish_shim::devAlloc<glm::vec3>((size_t)width * height);
 }
-inline void LeveledEAWFilter::destroy() { hipFree(tmpImg); tmpImg = nullptr; }
+inline void LeveledEAWFilter::destroy() { radish_shim::devFree(tmpImg); }
 inline void LeveledEAWFilter::filter(glm::vec3 *&colorOut, glm::vec3 *colorIn, const GBuffer &gBuffer, const Camera &cam) {
     waveletFilter.filter(colorOut, colorIn, gBuffer, cam, 0);  // :419-434
     for (int lv = 1; lv <= 4; lv++) {
@@ -211,8 +249,8 @@ inline void SpatioTemporalFilter::create(int width, int height, int level) {  //
     filteredVar = radish_shim::devAlloc<float>((size_t)width * height);
 }
 inline void SpatioTemporalFilter::destroy() {  // :450-459
-    for (int i = 0; i < 2; i++) { hipFree(accumColor[i]); hipFree(accumMoment[i]); }
-    hipFree(variance); hipFree(tmpColor); hipFree(tmpVar); hipFree(filteredVar);
+    for (int i = 0; i < 2; i++) { radish_shim::devFree(accumColor[i]); radish_shim::devFree(accumMoment[i]); }
+    radish_shim::devFree(variance); radish_shim::devFree(tmpColor); radish_shim::devFree(tmpVar); radish_shim::devFree(filteredVar);
 }
 inline void SpatioTemporalFilter::temporalAccumulate(glm::vec3 *colorIn, const GBuffer &gBuffer) {  // :461-485
     rdh_gbuffer g = radish_shim::toC(gBuffer);
@@ -248,4 +286,4 @@ inline void SpatioTemporalFilter::filter(glm::vec3 *&colorOut, glm::vec3 *colorI
 }
 inline void SpatioTemporalFilter::nextFrame() { frameIdx ^= 1; }  // :560
 #endif  // RADISH_SHIM_WITH_DENOISER
-#endif
+#endif  // RADISH_SHIM_HELPERS_ONLY

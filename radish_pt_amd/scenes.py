@@ -16,24 +16,27 @@ from . import hostlib
 from . import layouts as L
 
 _CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cache")
+_DIRS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "sobol_dirs_200x32.u32")
 
 
 def sobol_table():
     """uint32[10000][200] Joe–Kuo Sobol' points, unscrambled (stand-in for the absent sobol_10k_200.bin,
-    `/root/reference/src/scene.cpp:543-548`).  scipy's bundled direction numbers; x * 2^32 is an exact integer."""
+    `/root/reference/src/scene.cpp:543-548`), generated from the committed direction numbers
+    (`data/sobol_dirs_200x32.u32`: v[dim][bit], 25.6 KB, taken from scipy's bundled Joe–Kuo table) by the Gray-code
+    recurrence x[i] = x[i-1] XOR v[:, index of the lowest zero bit of i-1].  The 8 MB table itself is a run-time cache, not
+    a tracked file; tests/test_golden.py checks the first points against scipy and the published Joe–Kuo values."""
     path = os.path.join(_CACHE, "sobol_10k_200.bin")
     if os.path.exists(path):
         t = np.fromfile(path, dtype="<u4")
         if t.size == L.SOBOL_NUM * L.SOBOL_DIM:
             return t.reshape(L.SOBOL_NUM, L.SOBOL_DIM)
-    import warnings
-
-    from scipy.stats import qmc
-
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        x = qmc.Sobol(d=L.SOBOL_DIM, scramble=False, bits=32).random(L.SOBOL_NUM)
-    t = (x * 4294967296.0).astype(np.uint64).astype("<u4")
+    v = np.fromfile(_DIRS, dtype="<u4").reshape(L.SOBOL_DIM, 32)
+    t = np.zeros((L.SOBOL_NUM, L.SOBOL_DIM), dtype="<u4")
+    cur = np.zeros(L.SOBOL_DIM, dtype="<u4")
+    for i in range(1, L.SOBOL_NUM):
+        c = (~(i - 1) & i).bit_length() - 1
+        cur = cur ^ v[:, c]
+        t[i] = cur
     try:
         os.makedirs(_CACHE, exist_ok=True)
         t.tofile(path)

@@ -8,7 +8,7 @@ of every bit.  Each test also reports the fraction of pixels outside 1e-4 relati
 import numpy as np
 import pytest
 
-from helpers import assert_bit_equal, random_rays, random_segments
+from helpers import assert_bit_equal, random_rays, random_segments, restir_partition_run as _restir_partition_run
 
 pytestmark = pytest.mark.gpu
 
@@ -511,58 +511,6 @@ def test_tile_partition_matches_frame(gpu_ctx, cornell_small):
         assert_bit_equal(frame_d.cpu().numpy(), full_d.cpu().numpy(), f"world={world} direct")
         assert_bit_equal(frame_i.cpu().numpy(), full_i.cpu().numpy(), f"world={world} indirect")
     gpu_ctx.set_partition(0, 1, 64)
-
-
-def _restir_partition_run(gpu_ctx, sd, W, H, cams, world, tile, reuse):
-    """ReSTIR frames on `world` virtual ranks (one rdh_ctx each, all on this GPU): whole-frame G-buffer, rdh_restir_direct per
-    rank into its packed tiles, reservoir exchange (pack -> simulated all-gather -> unpack), rdh_untile.  Returns the frames and
-    every rank's `last` reservoirs after each frame."""
-    from radish_pt_amd import api
-
-    torch = _torch()
-    n = W * H
-    dev = api.DevScene()
-    ctxs = []
-    for rank in range(world):
-        c = gpu_ctx if world == 1 else api.Context(0)
-        c.upload_scene(sd)
-        c.set_partition(rank, world, tile)
-        c.set_camera(cams[0])
-        c.restir_init()
-        ctxs.append(c)
-    gb = api.GBuffer()
-    gb.create(W, H)
-    frames, resv = [], []
-    tpr = ctxs[0].tiles_per_rank()
-    imgs = [torch.zeros(n if world == 1 else tpr * tile * tile, 3, device="cuda") for _ in ctxs]
-    for f, cam in enumerate(cams):
-        dev.ctx = ctxs[0]
-        gb.render(dev, cam)  # whole frame regardless of the partition
-        for c, img in zip(ctxs, imgs):
-            c.set_camera(cam)
-            c.restir_direct(img, 0, 40 + f, gb.c_struct(cam), reuse)
-        if world == 1:
-            frames.append(imgs[0].cpu().numpy().copy())
-        else:
-            packs = []
-            for c in ctxs:
-                pk = torch.zeros(tpr * tile * tile, 9, device="cuda")
-                c.restir_exchange_pack(pk)
-                packs.append(pk)
-            gathered = torch.cat(packs).contiguous()
-            for c in ctxs:
-                c.restir_exchange_unpack(gathered)
-            frame = torch.zeros(n, 3, device="cuda")
-            ctxs[0].untile(torch.cat(imgs).contiguous(), frame)
-            ctxs[0].synchronize()
-            frames.append(frame.cpu().numpy().copy())
-        resv.append([c.restir_read(1).tobytes() for c in ctxs])
-        gb.update(cam)
-    for c in ctxs:
-        c.restir_free()
-        if c is not gpu_ctx:
-            c.close()
-    return frames, resv
 
 
 def test_restir_tile_partition_matches_frame(gpu_ctx):
