@@ -1484,4 +1484,43 @@ void orc_camera_sample(const void *camera196, int x, int y, const float *r4, flo
     ray6[3] = r.direction.x; ray6[4] = r.direction.y; ray6[5] = r.direction.z;
 }
 
+// ---- known-answer-test hooks for the light sampler and the reservoir arithmetic (tests/test_oracle_float64.py) ------------
+void orc_sample_direct_light(orc_scene *s, const float *pos3, const float *r4, int visibility, float *radiance3, float *wi3,
+                             float *dist, float *pdf) {
+    SceneView scene{s};
+    vec3 radiance(0.f), wi(0.f);
+    float d = 0.f;
+    vec3 pos(pos3[0], pos3[1], pos3[2]);
+    vec4 r{r4[0], r4[1], r4[2], r4[3]};
+    *pdf = visibility ? scene.sampleDirectLight(pos, r, radiance, wi) : scene.sampleDirectLightNoVisibility(pos, r, radiance, wi, d);
+    radiance3[0] = radiance.x; radiance3[1] = radiance.y; radiance3[2] = radiance.z;
+    wi3[0] = wi.x; wi3[1] = wi.y; wi3[2] = wi.z;
+    *dist = d;
+}
+void orc_reservoir_op(int op, void *r36, const void *rhs36, float rnd, int M) {
+    DirectReservoir r, rhs;
+    memcpy(&r, r36, sizeof(r));
+    memcpy(&rhs, rhs36, sizeof(rhs));
+    switch (op) {
+        case 0: resvMerge(r, rhs, rnd); break;
+        case 1: resvPreClampedMerge(r, rhs, rnd, M); break;
+        case 2: resvUpdate(r, rhs.sample, rhs.weight, rnd, true); break;   // rhs carries {newSample, newWeight}
+        case 3: resvUpdate(r, rhs.sample, rhs.weight, rnd, false); break;
+        case 4: resvCheckValidity(r); break;
+        default: break;
+    }
+    memcpy(r36, &r, sizeof(r));
+}
+float orc_reservoir_W(const void *r36, const void *material44, const float *n3, const float *wo3) {
+    DirectReservoir r;
+    Material m;
+    memcpy(&r, r36, sizeof(r));
+    memcpy(&m, material44, sizeof(m));
+    Intersection isec{};
+    isec.norm = vec3(n3[0], n3[1], n3[2]);
+    isec.wo = vec3(wo3[0], wo3[1], wo3[2]);
+    return resvW(r, isec, m);
+}
+float orc_power_heuristic(float f, float g) { return powerHeuristic(f, g); }
+
 }  // extern "C"

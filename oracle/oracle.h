@@ -138,6 +138,16 @@ void orc_texture_sample(orc_scene *s, int texId, const float *uv2, float *rgb3);
 void orc_material_eval(const void *material44, int which, const float *n3, const float *wo3, const float *wi_or_r3,
                        float *out8);
 void orc_camera_sample(const void *camera196, int x, int y, const float *r4, float *ray6);
+/* Light sampler: sampleDirectLight (scene.h:419-456, visibility != 0: traces the shadow ray) / sampleDirectLightNoVisibility
+ * (:458-492); returns the pdf (INVALID_PDF = -1 when rejected), radiance, wi, dist (NoVisibility only). */
+void orc_sample_direct_light(orc_scene *s, const float *pos3, const float *r4, int visibility, float *radiance3, float *wi3,
+                             float *dist, float *pdf);
+/* Reservoir arithmetic (restir.h:10-92) on 36-byte DirectReservoir records: op 0 merge(rhs, rnd), 1 preClampedMerge<M>(rhs, rnd),
+ * 2 update(rhs.sample, rhs.weight, rnd) as written (truthiness test, :21), 3 update with the corrected `<` test, 4 checkValidity. */
+void orc_reservoir_op(int op, void *r36, const void *rhs36, float rnd, int M);
+/* Reservoir::W (restir.h:37-40) at a surface with normal n, outgoing direction wo and the 44-byte Material. */
+float orc_reservoir_W(const void *r36, const void *material44, const float *n3, const float *wo3);
+float orc_power_heuristic(float f, float g); /* Math::powerHeuristic (mathUtil.h:81-84) */
 
 #ifdef __cplusplus
 }

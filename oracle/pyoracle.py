@@ -79,6 +79,11 @@ def lib():
         l.orc_texture_sample.argtypes = [vp, i32, vp, vp]
         l.orc_material_eval.argtypes = [vp, i32, vp, vp, vp, vp]
         l.orc_camera_sample.argtypes = [vp, i32, i32, vp, vp]
+        l.orc_sample_direct_light.argtypes = [vp, vp, vp, i32, vp, vp, C.POINTER(f32), C.POINTER(f32)]
+        l.orc_sample_direct_light.restype = None
+        l.orc_reservoir_op.argtypes, l.orc_reservoir_op.restype = [i32, vp, vp, f32, i32], None
+        l.orc_reservoir_W.argtypes, l.orc_reservoir_W.restype = [vp, vp, vp, vp], f32
+        l.orc_power_heuristic.argtypes, l.orc_power_heuristic.restype = [f32, f32], f32
         l.orc_copy_image_to_pbo.argtypes = [vp, vp, i32, i32, i32, i32, f32]
         l.orc_copy_image_to_pbo.restype = None
         l.orc_pow_gamma.argtypes = [f32]
@@ -181,6 +186,16 @@ class OracleScene:
         s = Stats()
         lib().orc_stats_get(self.h, C.byref(s))
         return s.as_dict()
+
+    def sample_direct_light(self, pos, r4, visibility):
+        """(pdf, radiance[3], wi[3], dist) of sampleDirectLight / sampleDirectLightNoVisibility at `pos` with draws r4."""
+        pos = np.ascontiguousarray(pos, np.float32)
+        r4 = np.ascontiguousarray(r4, np.float32)
+        rad, wi = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        dist, pdf = C.c_float(0), C.c_float(0)
+        lib().orc_sample_direct_light(self.h, pos.ctypes.data, r4.ctypes.data, int(visibility), rad.ctypes.data, wi.ctypes.data,
+                                      C.byref(dist), C.byref(pdf))
+        return pdf.value, rad, wi, dist.value
 
     def trace_closest(self, rays, naive=False):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
@@ -290,3 +305,23 @@ def denoise_filter_variance(var_in, width, height):
     out = np.zeros_like(var_in)
     lib().orc_denoise_filter_variance(out.ctypes.data, var_in.ctypes.data, width, height)
     return out
+
+
+def reservoir_op(op, r, rhs, rnd, M=20):
+    """restir.h's reservoir arithmetic on one-element RESERVOIR_DTYPE arrays (see orc_reservoir_op); returns the new `r`."""
+    out = np.array(r, copy=True)
+    rhs = np.ascontiguousarray(rhs)
+    lib().orc_reservoir_op(int(op), out.ctypes.data, rhs.ctypes.data, float(rnd), int(M))
+    return out
+
+
+def reservoir_W(r, material, n, wo):
+    r = np.ascontiguousarray(r)
+    m = np.ascontiguousarray(material)
+    n = np.ascontiguousarray(n, np.float32)
+    wo = np.ascontiguousarray(wo, np.float32)
+    return float(lib().orc_reservoir_W(r.ctypes.data, m.ctypes.data, n.ctypes.data, wo.ctypes.data))
+
+
+def power_heuristic(f, g):
+    return float(lib().orc_power_heuristic(float(f), float(g)))
