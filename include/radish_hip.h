@@ -102,6 +102,8 @@ typedef struct rdh_counters {
                                   instead of setting them aside for the workgroup-per-ray launch (k_gbuffer_literal)   */
 #define RDH_PT_PARTITION_GBUFFER 512u /* rdh_gbuffer_render on a tile partition: render the records of THIS rank's tiles only
                                   (complete the planes with rdh_gbuffer_exchange*); default: every rank renders the whole frame */
+#define RDH_PT_RESTIR_FUSED 1024u /* rdh_restir_direct: round 1's pass 1, one lane per pixel with both walks inside the kernel
+                                  (k_restir_pass1), instead of raygen / walk / RIS / walk / resolve (default; same results) */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read            */

@@ -34,6 +34,7 @@ RDH_PT_MEGA_GBUFFER = RDH_PT_ONE_LANE_PER_PIXEL
 RDH_PT_NO_DEFER = 128
 RDH_PT_WG_PER_RAY = 256
 RDH_PT_PARTITION_GBUFFER = 512
+RDH_PT_RESTIR_FUSED = 1024
 SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12
 
 # Every symbol include/radish_hip.h declares (tests check that the library exports all of them).

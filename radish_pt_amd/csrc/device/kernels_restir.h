@@ -251,4 +251,237 @@ __global__ __launch_bounds__(256) void k_restir_pass2(DScene s, PixelMap pm, int
                  directIllum, iter, status == -1 ? mk3(s0.x, s0.y, s0.z) : mk3(0.f), s2.y, s2.z, px.out);
 }
 
+// =====================================================================================================================
+// Pass 1 as five launches (the default since round 2): the two WALKS leave the pixel kernel.
+//
+//   k_restir_raygen   jittered primary ray of every pixel of the launch domain           -> ray list    (24 B / slot)
+//   k_walk_persistent closest hit of the list (lane refill, 8 waves per SIMD)            -> hit records (16 B)
+//   k_restir_ris      surface fetch, 32-candidate RIS from an LDS-resident light table   -> raw reservoir, shadow segment, state
+//   k_walk_persistent any hit of the shadow segments                                     -> occlusion flags (4 B)
+//   k_restir_resolve  visibility, temporal merge, the two reservoir stores (restir.cu:158-187)
+//
+// In the fused kernel (k_restir_pass1 above, still there behind RDH_PT_RESTIR_FUSED) a pixel keeps its lane for the whole
+// launch: every wave waits for its longest primary ray and again for its longest shadow ray, at the 4-5 waves per SIMD the
+// RIS / BSDF code's registers allow (2.67 ms of the 3.69-ms config-4 frame in round 1, 2.0 ms of it the two walks).  The
+// walk-only kernel refills lanes and runs at 8 waves per SIMD; the RIS kernel has no walk in it.  Every pixel still executes
+// restir.cu:111-187 in order — same draws, same arithmetic — so images and reservoirs are bit-identical to the fused kernel
+// and to the oracle.  A "slot" is the linear index block * 64 + lane of the launch domain (this rank's 8x8 blocks, or its
+// apron blocks); everything handed from launch to launch is indexed by slot, not by pixel, because apron blocks of
+// neighbouring own tiles can cover the same pixel twice.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_light_precompute(const LightRec *__restrict__ lights, LightPre *__restrict__ out, int n,
+                                                          float sumLightPowerInv) {
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const float4 A = lights[i].a, B = lights[i].b, C = lights[i].c;
+    const v3 v0 = mk3(A.x, A.y, A.z), v1 = mk3(A.w, B.x, B.y), v2_ = mk3(B.z, B.w, C.x);
+    const v3 normal = triangleNormal(v0, v1, v2_);
+    const float area = triangleArea(v0, v1, v2_);
+    const float power = luminance(mk3(C.y, C.z, C.w)) / (area * 2.f * PI_F);  // scene.h:489
+    out[i].a = A;
+    out[i].b = B;
+    out[i].c = C;
+    out[i].d = make_float4(normal.x, normal.y, normal.z, power * sumLightPowerInv);
+}
+
+// Is this ray one the walker sets aside (k_walk_persistent<.., DEFER>)?  Its slab-test class, from the ray the walker will build.
+RD_DEV bool restirRayIsLiteral(v3 a, v3 b, bool any) {
+    Ray ray;
+    if (any) {  // testOcclusion's set-up (scene.h:304-311)
+        v3 dir = b - a;
+        float dist = length(dir);
+        dir = dir / dist;
+        ray = makeOffsetedRay(a, dir);
+    } else {
+        ray = Ray{a, b};
+    }
+    return makeRaySlab(ray).cls != 0;
+}
+constexpr int kRestirDeferCap = 256;  // == kWalkDeferCap (kernels_walk.h)
+
+struct RestirSplit {  // per-slot scratch between the launches of pass 1
+    float *rays;       // 6 floats: origin, direction (NaN origin.x: no ray)
+    int4 *hits;        // rdh_hit of the primary ray
+    float *segs;       // 6 floats: shadow segment x, y (NaN: none)
+    int *occ;          // 1 = the shadow segment is occluded
+    float *rawResv;    // 9 floats: the reservoir after RIS, before visibility
+    float4 *st;        // 3 x float4, as RestirArgs::state
+    int *deferCount;   // [0] literal-class primary rays, [1] literal-class shadow segments of this frame
+    int *deferList;    // [0 .. cap) slots of the primary rays, [cap .. 2 cap) of the shadow segments
+};
+
+RD_DEV Pix restirPixel(const PixelMap &pm, unsigned blk, unsigned lane, int apronBlocks) {
+    const unsigned nBlocks = apronBlocks > 0 ? (unsigned)apronBlocks : (unsigned)pm.numBlocks;
+    Pix px = apronBlocks > 0 ? mapPixelApron(pm, blk, lane) : mapPixel(pm, blk, lane);
+    px.valid = px.valid && blk < nBlocks;
+    return px;
+}
+
+__global__ __launch_bounds__(256) void k_restir_raygen(DScene s, DCamera cam, PixelMap pm, int looper, int apronBlocks,
+                                                       float *__restrict__ rays, int *__restrict__ deferCount,
+                                                       int *__restrict__ deferList) {
+    const unsigned blk = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const unsigned nBlocks = apronBlocks > 0 ? (unsigned)apronBlocks : (unsigned)pm.numBlocks;
+    if (blk >= nBlocks) return;
+    const Pix px = restirPixel(pm, blk, lane, apronBlocks);
+    float *o = rays + 6ll * (blk * 64u + lane);
+    if (!px.valid) {
+        o[0] = __builtin_nanf("");
+        return;
+    }
+    Sampler rng = makeSeededRandomEngine(looper, px.index, 0, s.sobol);
+    const Ray ray = cameraSample(cam, px.x, px.y, sample4D(rng));  // restir.cu:111-113
+    o[0] = ray.o.x; o[1] = ray.o.y; o[2] = ray.o.z;
+    o[3] = ray.d.x; o[4] = ray.d.y; o[5] = ray.d.z;
+    if (s.bvhSize != 0 && restirRayIsLiteral(ray.o, ray.d, false)) {
+        const int at = atomicAdd(&deferCount[0], 1);
+        if (at < kRestirDeferCap) deferList[at] = int(blk * 64u + lane);
+    }
+}
+
+// sampleDirectLightNoVisibility (scene.h:458-492) with the light's record, plain normal and area pdf read from LDS.
+RD_DEV float risCandidateStaged(const float4 *ldsLights, int lightId, v3 pos, float rz, float rw, v3 &radiance, v3 &wi, float &dist) {
+    const float4 A = ldsLights[4 * lightId], B = ldsLights[4 * lightId + 1], C = ldsLights[4 * lightId + 2], D = ldsLights[4 * lightId + 3];
+    const v3 v0 = mk3(A.x, A.y, A.z), v1 = mk3(A.w, B.x, B.y), v2_ = mk3(B.z, B.w, C.x);
+    const v3 sampled = sampleTriangleUniform(v0, v1, v2_, rz, rw);
+    const v3 normal = mk3(D.x, D.y, D.z);
+    const v3 posToSampled = sampled - pos;
+    if (dot(normal, posToSampled) > -1e-6f) return INVALID_PDF;
+    radiance = mk3(C.y, C.z, C.w);
+    wi = normalize(posToSampled);
+    dist = length(posToSampled);
+    return pdfAreaToSolidAngle(D.w, pos, sampled, normal);
+}
+
+constexpr int kRisThreads = 512;
+// STAGED: the alias table (8 B per entry) and the LightPre records (64 B per light) sit in LDS (1 026 lights: 74 KB; two
+// 512-thread workgroups per CU), staged once per workgroup; the workgroups are persistent (grid-stride over the 8x8 blocks).
+// Not STAGED (tables larger than kRisLdsBytes): the same loop on the global tables.
+constexpr unsigned kRisLdsBytes = 76u * 1024u;
+template <bool STAGED>
+__global__ __launch_bounds__(kRisThreads) void k_restir_ris(DScene s, DCamera cam, PixelMap pm, int looper, RestirArgs a, int apronBlocks,
+                                                            RestirSplit sp) {
+    extern __shared__ float4 ldsRaw[];
+    const int nLights = s.lightSamplerLength - (s.envSamplerLength != 0 ? 1 : 0);
+    const float4 *ldsLights = ldsRaw;
+    const AliasRec *ldsAlias = reinterpret_cast<const AliasRec *>(ldsRaw + 4 * nLights);
+    if (STAGED) {
+        const float4 *src = reinterpret_cast<const float4 *>(s.lightPre);
+        for (int i = int(threadIdx.x); i < 4 * nLights; i += kRisThreads) ldsRaw[i] = src[i];
+        AliasRec *dst = reinterpret_cast<AliasRec *>(ldsRaw + 4 * nLights);
+        for (int i = int(threadIdx.x); i < s.lightSamplerLength; i += kRisThreads) dst[i] = s.lightAlias[i];
+        __syncthreads();
+    }
+    const unsigned nBlocks = apronBlocks > 0 ? (unsigned)apronBlocks : (unsigned)pm.numBlocks;
+    const unsigned lane = threadIdx.x & 63u;
+    for (unsigned blk = blockIdx.x * (kRisThreads / 64) + (threadIdx.x >> 6); blk < nBlocks; blk += gridDim.x * (kRisThreads / 64)) {
+        const Pix px = restirPixel(pm, blk, lane, apronBlocks);
+        const long long slot = (long long)blk * 64 + lane;
+        float *seg = sp.segs + 6 * slot;
+        seg[0] = __builtin_nanf("");  // no shadow ray unless set below
+        if (!px.valid) continue;
+        Sampler rng = makeSeededRandomEngine(looper, px.index, 0, s.sobol);
+        const Ray ray = cameraSample(cam, px.x, px.y, sample4D(rng));
+        const int4 hr = sp.hits[slot];
+        int status = -1;
+        Surface isec;
+        isec.norm = mk3(0.f);
+        isec.wo = mk3(0.f);
+        v3 missDirect = mk3(0.f);
+        float texMetallic = 0.f, texRoughness = 0.f;
+        if (hr.x == -1 && hasEnvMap(s)) missDirect = envLookup(s, ray.d);  // restir.cu:117-122
+        if (hr.x != -1) {
+            fetchSurface(s, hr.x, mk2(__int_as_float(hr.y), __int_as_float(hr.z)), isec);
+            Material material = texturedMaterial(s, isec);
+            material.baseColor = mk3(1.f);  // :125
+            texMetallic = material.metallic;
+            texRoughness = material.roughness;
+            if (material.type == Light) {
+                status = -2;
+            } else {
+                status = isec.matId;
+                isec.wo = -ray.d;
+                const bool deltaBSDF = (material.type == Dielectric);
+                if (!deltaBSDF && dot(isec.norm, isec.wo) < 0.f) isec.norm = -isec.norm;
+                Reservoir reservoir = emptyReservoir();
+                for (int i = 0; i < a.risCount; ++i) {  // :139-156
+                    v3 Li = mk3(0.f), wi = mk3(0.f);  // defined instead of uninitialised
+                    float dist = 0.f;
+                    const v4 r4 = sample4D(rng);
+                    float lightPdf;
+                    if (STAGED) {
+                        lightPdf = INVALID_PDF;
+                        if (s.lightSamplerLength != 0) {
+                            const int length = s.lightSamplerLength;  // DevDiscreteSampler1D::sample, sampler.h:204-208
+                            const int passId = imin(int(float(length) * r4.x), length - 1);
+                            const AliasRec d = ldsAlias[passId];
+                            const int lightId = (r4.y < d.prob) ? passId : d.failId;
+                            if (lightId == length - 1 && s.envSamplerLength != 0)  // the environment map: not staged
+                                lightPdf = sampleDirectLightNoVisibility(s, isec.pos, r4, Li, wi, dist);
+                            else
+                                lightPdf = risCandidateStaged(ldsLights, lightId, isec.pos, r4.z, r4.w, Li, wi, dist);
+                        }
+                    } else {
+                        lightPdf = sampleDirectLightNoVisibility(s, isec.pos, r4, Li, wi, dist);
+                    }
+                    const v3 bsdf = Li * materialBSDF(material, isec.norm, isec.wo, wi) * satDot(isec.norm, wi);
+                    float weight = length(bsdf / lightPdf);
+                    if (isNanOrInf(weight) || lightPdf <= 0.f) weight = 0.f;
+                    resvUpdate(reservoir, LightLiSample{Li, wi, dist}, weight, rng.sample(), a.faithfulRIS != 0);
+                }
+                const LightLiSample smp = reservoir.sample;
+                const v3 target = isec.pos + smp.wi * smp.dist;  // the shadow segment of :160-163
+                seg[0] = isec.pos.x; seg[1] = isec.pos.y; seg[2] = isec.pos.z;
+                seg[3] = target.x; seg[4] = target.y; seg[5] = target.z;
+                if (s.bvhSize != 0 && restirRayIsLiteral(isec.pos, target, true)) {
+                    const int at = atomicAdd(&sp.deferCount[1], 1);
+                    if (at < kRestirDeferCap) sp.deferList[kRestirDeferCap + at] = int(slot);
+                }
+                storeReservoir(sp.rawResv, slot, reservoir);
+            }
+        }
+        sp.st[3 * slot + 0] = (status == -1) ? make_float4(missDirect.x, missDirect.y, missDirect.z, 0.f)
+                                            : make_float4(isec.norm.x, isec.norm.y, isec.norm.z, isec.wo.x);
+        sp.st[3 * slot + 1] = make_float4(isec.wo.y, isec.wo.z, __uint_as_float(rng.scramble), __int_as_float(rng.ptr));
+        sp.st[3 * slot + 2] = make_float4(__int_as_float(status), texMetallic, texRoughness, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_restir_resolve(DScene s, PixelMap pm, int iter, RestirArgs a, int apronBlocks, RestirSplit sp,
+                                                        float *__restrict__ directIllum) {
+    const unsigned blk = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const Pix px = restirPixel(pm, blk, lane, apronBlocks);
+    if (!px.valid) return;
+    const long long slot = (long long)blk * 64 + lane;
+    const int idx = px.index;
+    const bool doSpatial = (a.reuseMask & 2) != 0;
+    const float4 s0 = sp.st[3 * slot + 0], s1 = sp.st[3 * slot + 1], s2 = sp.st[3 * slot + 2];
+    const int status = __float_as_int(s2.x);
+    Sampler rng{s.sobol, __float_as_uint(s1.z), __float_as_int(s1.w)};
+    Reservoir reservoir = emptyReservoir();
+    if (status >= 0) {
+        reservoir = loadReservoir(sp.rawResv, slot);
+        if (sp.occ[slot] != 0) reservoir.weight = 0.f;  // :158-163
+        if (!a.firstFrame && (a.reuseMask & 1)) {       // :165-170
+            Reservoir temporal = findTemporalNeighbor(a, idx);
+            if (!resvInvalid(temporal)) resvPreClampedMerge(reservoir, temporal, rng.sample(), a.temporalClamp);
+        }
+        Reservoir tempReservoir = reservoir;
+        if (doSpatial) {
+            resvCheckValidity(reservoir);
+            storeReservoir(a.reservoirTemp, idx, reservoir);  // :176-177
+        }
+        resvCheckValidity(tempReservoir);
+        storeReservoir(a.reservoirOut, idx, tempReservoir);  // :186-187
+    }
+    if (doSpatial) {
+        a.state[3 * (long long)idx + 0] = s0;
+        a.state[3 * (long long)idx + 1] = make_float4(s1.x, s1.y, __uint_as_float(rng.scramble), __int_as_float(rng.ptr));
+        a.state[3 * (long long)idx + 2] = s2;
+    } else {
+        restirFinish(s, a, idx, status, mk3(s0.x, s0.y, s0.z), mk3(s0.w, s1.x, s1.y), reservoir, rng, px.x, px.y, false, directIllum,
+                     iter, status == -1 ? mk3(s0.x, s0.y, s0.z) : mk3(0.f), s2.y, s2.z, px.out);
+    }
+}
+
 }  // namespace rd

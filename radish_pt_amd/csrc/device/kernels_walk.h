@@ -14,13 +14,21 @@ namespace rd {
 #ifndef RD_WALK_REFILL_MIN
 #define RD_WALK_REFILL_MIN 16  // refill once this many lanes are idle
 #endif
+#ifndef RD_WALK_PAIR_FETCH
+#define RD_WALK_PAIR_FETCH 0  // 1: lane pairs share the two requests of a box step (traverse.h, fetchNodePaired)
+#endif
 #ifndef RD_WALK_FINISH_MIN
 #define RD_WALK_FINISH_MIN 8  // retire once done lanes * 64 >= busy lanes * this
 #endif
 
-template <bool COUNT, bool ANY>
+// DEFER (ReSTIR's ray lists): literal-class rays — one wave needs ~1 ms for one of them on the teapots scene, which is then the
+// duration of the whole launch — have been listed by the kernel that wrote the rays (at most kWalkDeferCap of them, else none is
+// set aside) and are traced by k_trace_wg_list, one 1 024-thread workgroup each, on a second stream beside this launch.
+constexpr int kWalkDeferCap = 256;
+template <bool COUNT, bool ANY, bool DEFER = false>
 __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,
-                                                        int *__restrict__ occluded, PersistCounters *pc) {
+                                                        int *__restrict__ occluded, PersistCounters *pc,
+                                                        const int *__restrict__ deferCount = nullptr) {
     const int lane = int(threadIdx.x) & 63;
     const int end = s.bvhSize;
     const long long chunks = (n + 63) / 64;
@@ -38,11 +46,18 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
     rs.o = rs.d = rs.inv = mk3(0.f);
     rs.cls = 0;
     const NodeRec *nodes = s.nodes[0];
+#if RD_WALK_PAIR_FETCH
+    const char *nodeBase = reinterpret_cast<const char *>(s.nodes[0]);  // all six orderings are one allocation (layouts.h)
+    const unsigned ordStride = (unsigned)(s.bvhSize + 1) * (unsigned)sizeof(NodeRec);
+    unsigned ordOfs = 0;
+    const bool oddLane = (lane & 1) != 0;
+#endif
     int node = end, pending = -1;
     float tmax = 0.f;
     int hitPrim = -1;
     v2 hitBary = mk2(0.f, 0.f);
     bool found = false;
+    const bool deferAll = DEFER && *deferCount <= kWalkDeferCap;  // written by the kernel that produced the list, earlier in the stream
 
     for (;;) {
         // ---------------- new rays for idle lanes ----------------
@@ -66,7 +81,9 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
                 const int give = (nIdle - taken) < avail ? (nIdle - taken) : avail;
                 if (state == W_IDLE && myRank >= taken && myRank < taken + give) {
                     const long long i = curChunk * 64 + slotNext + (myRank - taken);
-                    if (i < n) {
+                    // a NaN in the first float marks an empty slot of the list (ReSTIR's per-slot ray lists): no ray, no record,
+                    // nothing counted
+                    if (i < n && rays[6 * i] == rays[6 * i]) {
                         rayIdx = i;
                         const v3 a = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
                         const v3 b = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
@@ -83,13 +100,18 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
                         }
                         rs = makeRaySlab(ray);
                         nodes = s.nodes[getMTBVHId(-ray.d)];
+#if RD_WALK_PAIR_FETCH
+                        ordOfs = (unsigned)getMTBVHId(-ray.d) * ordStride;
+#endif
                         node = 0;
                         pending = -1;
                         hitPrim = -1;
                         hitBary = mk2(0.f, 0.f);
                         found = false;
-                        nRays++;
-                        state = W_TRACE;
+                        if (!(DEFER && deferAll && rs.cls != 0 && end != 0)) {  // else: k_trace_wg_list has this ray
+                            nRays++;
+                            state = W_TRACE;
+                        }
                     }
                 }
                 slotNext += give;
@@ -136,17 +158,25 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
             } else if (nStart > 0) {
                 const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
                 do {
+#if RD_WALK_PAIR_FETCH
+                    float4 lo, hi;  // the record's two corners, in either order (see fetchNodePaired)
+                    int recPrim, recNext;
+                    fetchNodePaired(nodeBase, ordOfs + ((unsigned)node << 5), walking, oddLane, lo, hi, recPrim, recNext);
+#endif
                     if (walking) {
+#if !RD_WALK_PAIR_FETCH
                         float4 lo = nodes[node].lo_prim;
                         float4 hi = nodes[node].hi_next;
+                        const int recPrim = __float_as_int(lo.w), recNext = __float_as_int(hi.w);
+#endif
                         float boundDist;
                         if (COUNT) ws.nodes++;
                         bool boundHit = aabbFast(lo, hi, rs, boundDist);
                         if (boundHit && boundDist < tmax) {
-                            pending = __float_as_int(lo.w);
+                            pending = recPrim;
                             node++;
                         } else {
-                            node = __float_as_int(hi.w);
+                            node = recNext;
                         }
                         walking = pending < 0 && node != end;
                     }
@@ -238,4 +268,47 @@ __global__ __launch_bounds__(kWgTraceThreads) void k_trace_wg(DScene s, const fl
     }
 }
 
+// k_trace_wg over an index list (the literal-class rays a producer kernel set aside): list[0 .. *count) are indices into `rays`.
+template <bool COUNT, bool ANY>
+__global__ __launch_bounds__(kWgTraceThreads) void k_trace_wg_list(DScene s, const float *__restrict__ rays, const int *__restrict__ list,
+                                                                   const int *__restrict__ count, int4 *__restrict__ hits,
+                                                                   int *__restrict__ occluded) {
+    __shared__ WgTraceShared sh;
+    const int n = *count;
+    if (n > kWalkDeferCap) return;  // the walker traces them all in place
+    for (int k = int(blockIdx.x); k < n; k += int(gridDim.x)) {
+        const long long i = list[k];
+        const v3 a = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+        const v3 b = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+        Ray ray;
+        float tmax;
+        if (ANY) {
+            v3 dir = b - a;
+            float dist = length(dir);
+            dir = dir / dist;
+            ray = makeOffsetedRay(a, dir);
+            tmax = dist - 1e-4f;
+        } else {
+            ray = Ray{a, b};
+            tmax = 3.402823466e+38f;
+        }
+        const RaySlab rs = makeRaySlab(ray);
+        CoopTrace ct = wgTraceWhole<ANY>(s, s.nodes[getMTBVHId(-ray.d)], rs, tmax, sh);
+        if (threadIdx.x == 0) {
+            if (ANY) {
+                occluded[i] = ct.found ? 1 : 0;
+            } else {
+                const bool hit = ct.hitPrim != -1;
+                hits[i] = make_int4(ct.hitPrim, __float_as_int(hit ? ct.bary.x : 0.f), __float_as_int(hit ? ct.bary.y : 0.f),
+                                    __float_as_int(hit ? ct.tmax : 3.402823466e+38f));
+            }
+            if (COUNT) {
+                atomicAdd(ANY ? &s.counters->anyRays : &s.counters->closestRays, 1ull);
+                atomicAdd(&s.counters->nodeVisits, (unsigned long long)ct.nodes);
+                atomicAdd(&s.counters->triTests, (unsigned long long)ct.tris);
+                if (!ANY && ct.hitPrim != -1) atomicAdd(&s.counters->closestHits, 1ull);
+            }
+        }
+    }
+}
 }  // namespace rd

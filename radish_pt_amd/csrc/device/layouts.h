@@ -43,6 +43,15 @@ struct __attribute__((aligned(16))) LightRec {
 };
 static_assert(sizeof(LightRec) == 48, "LightRec");
 
+// The same light with what every RIS candidate would recompute from it — the plain normal (Math::triangleNormal) and the
+// area pdf `luminance(radiance) / (area * 2 pi) * sumLightPowerInv` of scene.h:489-491 — evaluated ONCE per scene by
+// k_light_precompute with the same device functions, hence the same bits.  64 B: what the ReSTIR RIS loop stages in LDS.
+struct __attribute__((aligned(16))) LightPre {
+    float4 a, b, c;  // as LightRec
+    float4 d;        // triangleNormal.xyz, power * sumLightPowerInv
+};
+static_assert(sizeof(LightPre) == 64, "LightPre");
+
 // Material (src/material.h:276-286) in three aligned quads.  48 B.
 struct __attribute__((aligned(16))) MatRec {
     float4 a;  // type (int bits), baseColor.xyz
@@ -65,6 +74,7 @@ struct DScene {
     const AttrRec *attrs;
     const MatRec *mats;
     const LightRec *lights;
+    const LightPre *lightPre;  // numLights records (no entry for the environment map)
     const AliasRec *lightAlias;
     const uint32_t *sobol;
     const float *texData;   // every texture's texels (vec3), concatenated (src/scene.cpp:464-480)

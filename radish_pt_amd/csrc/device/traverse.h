@@ -202,6 +202,37 @@ RD_DEV bool aabbFastPk(float4 lo, float4 hi, const RaySlabPk &r, float &tMin) {
     float tMax = __builtin_fminf(__builtin_fminf(fx, fy), fz);
     return overlap & (tMax >= 0.f) & (tMax >= tMin);
 }
+// ---- pair-shared node fetch -----------------------------------------------------------------------------------------------
+// The vector L1 prices a divergent gather per LANE REQUEST: a 64-lane dwordx4 load of 64 different lines costs ~27 ns of the
+// CU's L1 whatever its width, and a box step needs two of them per lane (the two halves of one 32-byte record) — 54 ns per
+// wave-step, the ceiling of every walker here (304 G box steps/s; scripts/micro/gather_modes.hip, mode 0).  Two lanes reading
+// the two halves of ONE record in the same instruction cost one request (mode 2: 16-19 ns for 32 records).  So lanes work in
+// pairs (2k, 2k+1): instruction 1 fetches the EVEN lane's record (even lane its low half, odd lane its high half), instruction 2
+// the ODD lane's record, and each lane takes the half it is missing from its partner with a DPP quad-permute (VALU, no LDS):
+// two requests per PAIR and step instead of four.  Must be called by all 64 lanes (uniform control flow).
+RD_DEV int dppSwapPairI(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); }  // quad_perm [1,0,3,2]
+RD_DEV float dppSwapPairF(float v) { return __int_as_float(dppSwapPairI(__float_as_int(v))); }
+// Returns the record's two halves as (mine, other): `mine` is the half this lane loaded itself (even lane: pMin | primitiveId,
+// odd lane: pMax | nextNodeIfMiss), `other` the half its partner loaded for it.  The slab test is symmetric in the two corners
+// (it only takes componentwise min / max of the two t vectors), so callers pass them in this order; `prim` and `next` are the
+// .w fields, sorted out here.  (DPP bank masks select groups of four consecutive lanes, not lane parity, hence the selects.)
+RD_DEV void fetchNodePaired(const char *base, unsigned ofs, bool walking, bool odd, float4 &mine, float4 &other, int &prim, int &next) {
+    const unsigned pofs = (unsigned)dppSwapPairI((int)ofs);
+    const bool pw = dppSwapPairI(walking ? 1 : 0) != 0;
+    const unsigned half = odd ? 16u : 0u;
+    const unsigned a1 = (odd ? pofs : ofs) + half;  // the even lane's record
+    const unsigned a2 = (odd ? ofs : pofs) + half;  // the odd lane's record
+    const bool need1 = odd ? pw : walking, need2 = odd ? walking : pw;
+    float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1;
+    if (need1) r1 = *reinterpret_cast<const float4 *>(base + a1);
+    if (need2) r2 = *reinterpret_cast<const float4 *>(base + a2);
+    mine = odd ? r2 : r1;
+    const float4 send = odd ? r1 : r2;
+    other = make_float4(dppSwapPairF(send.x), dppSwapPairF(send.y), dppSwapPairF(send.z), dppSwapPairF(send.w));
+    prim = __float_as_int(odd ? other.w : mine.w);
+    next = __float_as_int(odd ? mine.w : other.w);
+}
+
 RD_DEV unsigned long long ballotb(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // no bool -> int -> compare round trip
 
 // Out-of-line wrapper for the literal test: only rays with an axis-parallel, tiny or non-finite direction component

@@ -72,6 +72,11 @@ struct rdh_ctx {
     float *resvCur = nullptr, *resvLast = nullptr, *resvTemp = nullptr;
     float4 *restirState = nullptr;
     long long restirPixels = 0;
+    // per-slot scratch of the split pass 1 (kernels_restir.h RestirSplit), grown on demand
+    void *splitBuf = nullptr;
+    long long splitSlots = 0;
+    unsigned risGrid = 0;
+    LightPre *lightPre = nullptr;
     bool restirFirstFrame = true;
 
     // per-launch timing of the dominant (traversal) kernel: ring of hipEvent pairs (RDH_PT_PROFILE)
@@ -272,6 +277,55 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
         hipLaunchKernelGGL(k_wf_shade, dim3(c->wfGrid[3]), dim3(256), 0, c->stream, c->ds, w, k, maxDepth, sort ? 1 : 0);
     }
     hipLaunchKernelGGL(k_wf_finish, dim3(gridFor(pm)), dim3(256), 0, c->stream, pm, w, iter, d_direct, d_indirect);
+    return RDH_OK;
+}
+
+// k_walk_persistent over a ray list (d_hits xor d_occ): as many single-wave workgroups as stay resident, lane refill.
+// deferCount / deferList (ReSTIR's lists): literal-class rays have been listed by the producer of `d_rays`; they are traced one
+// per workgroup on the side stream beside the walker, which skips them; the stream waits for both before it goes on.
+int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *d_occ, bool count, const int *deferCount = nullptr,
+               const int *deferList = nullptr) {
+    const int any = d_occ ? 1 : 0;
+    if (deferCount) {
+        HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evFork, 0));
+        if (any && count) hipLaunchKernelGGL((k_trace_wg_list<true, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+        else if (any) hipLaunchKernelGGL((k_trace_wg_list<false, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+        else if (count) hipLaunchKernelGGL((k_trace_wg_list<true, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+        else hipLaunchKernelGGL((k_trace_wg_list<false, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+        HIP_TRY(c, hipEventRecord(c->evJoin, c->sideStream));
+    }
+    if (c->walkGrid[any] == 0) {
+        int perCU = 0, cus = 0;
+        if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, true>), 64, 0));
+        else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, false>), 64, 0));
+        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->walkGrid[any] = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
+    }
+    const unsigned long long chunks = (unsigned long long)((n + 63) / 64);
+    const unsigned grid = chunks < c->walkGrid[any] ? (unsigned)chunks : c->walkGrid[any];
+    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
+    if (deferCount) {
+        if (any && count)
+            hipLaunchKernelGGL((k_walk_persistent<true, true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount);
+        else if (any)
+            hipLaunchKernelGGL((k_walk_persistent<false, true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount);
+        else if (count)
+            hipLaunchKernelGGL((k_walk_persistent<true, false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount);
+        else
+            hipLaunchKernelGGL((k_walk_persistent<false, false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount);
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evJoin, 0));
+        return RDH_OK;
+    }
+    const int *none = nullptr;
+    if (any && count)
+        hipLaunchKernelGGL((k_walk_persistent<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none);
+    else if (any)
+        hipLaunchKernelGGL((k_walk_persistent<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none);
+    else if (count)
+        hipLaunchKernelGGL((k_walk_persistent<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none);
+    else
+        hipLaunchKernelGGL((k_walk_persistent<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none);
     return RDH_OK;
 }
 
@@ -501,6 +555,17 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
         lights[i].c = make_float4(v[8], r[0], r[1], r[2]);
     }
     if ((rc = uploadVec(c, lights, &c->ds.lights))) return rc;
+    {  // per-light constants of the RIS loop, computed on the device with the functions the per-candidate code uses
+        void *pre = nullptr;
+        HIP_TRY(c, hipMalloc(&pre, std::max<size_t>(sizeof(LightPre) * lights.size(), 64)));
+        c->sceneAllocs.push_back(pre);
+        c->ds.lightPre = static_cast<const LightPre *>(pre);
+        if (!lights.empty()) {
+            hipLaunchKernelGGL(k_light_precompute, dim3((unsigned)((lights.size() + 255) / 256)), dim3(256), 0, c->stream, c->ds.lights,
+                               static_cast<LightPre *>(pre), (int)lights.size(), d->sumLightPowerInv);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    }
     std::vector<AliasRec> alias(d->lightSamplerLength);
     if (d->lightSamplerLength) memcpy(alias.data(), d->lightSampler, sizeof(AliasRec) * alias.size());
     for (auto &e : alias)
@@ -749,6 +814,9 @@ int rdh_restir_free(rdh_ctx *c) {
     if (c->resvLast) hipFree(c->resvLast);
     if (c->resvTemp) hipFree(c->resvTemp);
     if (c->restirState) hipFree(c->restirState);
+    if (c->splitBuf) hipFree(c->splitBuf);
+    c->splitBuf = nullptr;
+    c->splitSlots = 0;
     c->resvCur = c->resvLast = c->resvTemp = nullptr;
     c->restirState = nullptr;
     c->restirPixels = 0;
@@ -815,16 +883,67 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
         int bpe = pm.tile / 8 + 2;
         apronBlocks = pm.tilesPerRank * bpe * bpe;
     }
-    const unsigned p1Threads = 64;  // single-wave workgroups, one 8x8 block each (kernels_restir.h)
-    const unsigned grid1 = (((unsigned)(apronBlocks > 0 ? apronBlocks : pm.numBlocks) + 7u) / 8u) * 8u;
+    const unsigned nBlocks1 = (unsigned)(apronBlocks > 0 ? apronBlocks : pm.numBlocks);
     timeBegin(c);
-    // One lane per pixel: a persistent lane-refill version of this pass (as for the G-buffer) was built and measured slower
-    // (3.21 ms against 2.90 ms on the teapots config): the 32-candidate RIS dominates, runs at full wave width here and at
-    // 32-48 lanes per batch there, and the state machine's 146 VGPRs cost two of this kernel's five waves per SIMD.
-    if (flags & RDH_PT_COUNT)
-        hipLaunchKernelGGL(k_restir_pass1<true>, dim3(grid1), dim3(p1Threads), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
-    else
-        hipLaunchKernelGGL(k_restir_pass1<false>, dim3(grid1), dim3(p1Threads), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
+    if (flags & RDH_PT_RESTIR_FUSED) {
+        // Round 1's pass 1: one lane per pixel for the whole launch, both walks inside it (k_restir_pass1).  A persistent
+        // lane-refill version of THAT kernel was measured slower (3.21 against 2.90 ms): the RIS loop dominates it.
+        const unsigned p1Threads = 64;  // single-wave workgroups, one 8x8 block each (kernels_restir.h)
+        const unsigned grid1 = ((nBlocks1 + 7u) / 8u) * 8u;
+        if (flags & RDH_PT_COUNT)
+            hipLaunchKernelGGL(k_restir_pass1<true>, dim3(grid1), dim3(p1Threads), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
+        else
+            hipLaunchKernelGGL(k_restir_pass1<false>, dim3(grid1), dim3(p1Threads), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
+    } else {
+        // raygen -> closest-hit walk -> RIS (LDS light table) -> any-hit walk -> resolve (kernels_restir.h)
+        const long long slots = (long long)nBlocks1 * 64;
+        constexpr size_t kSlotBytes = 24 + 16 + 24 + 4 + 36 + 48;
+        constexpr size_t kDeferBytes = 16 + 2 * sizeof(int) * kRestirDeferCap;
+        if (slots > c->splitSlots) {
+            if (c->splitBuf) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                hipFree(c->splitBuf);
+                c->splitBuf = nullptr;
+                c->splitSlots = 0;
+            }
+            HIP_TRY(c, hipMalloc(&c->splitBuf, (size_t)slots * kSlotBytes + kDeferBytes));
+            c->splitSlots = slots;
+        }
+        RestirSplit sp;
+        char *base = static_cast<char *>(c->splitBuf);
+        sp.st = reinterpret_cast<float4 *>(base);                                  // 48 B, 16-B aligned first
+        sp.hits = reinterpret_cast<int4 *>(base + (size_t)slots * 48);
+        sp.rays = reinterpret_cast<float *>(base + (size_t)slots * (48 + 16));
+        sp.segs = reinterpret_cast<float *>(base + (size_t)slots * (48 + 16 + 24));
+        sp.rawResv = reinterpret_cast<float *>(base + (size_t)slots * (48 + 16 + 24 + 24));
+        sp.occ = reinterpret_cast<int *>(base + (size_t)slots * (48 + 16 + 24 + 24 + 36));
+        sp.deferCount = reinterpret_cast<int *>(base + (size_t)slots * kSlotBytes);
+        sp.deferList = sp.deferCount + 4;
+        const bool defer = !(flags & RDH_PT_NO_DEFER);
+        HIP_TRY(c, hipMemsetAsync(sp.deferCount, 0, 16, c->stream));
+        const bool count = (flags & RDH_PT_COUNT) != 0;
+        const unsigned gridBlk = (nBlocks1 + 3u) / 4u;
+        hipLaunchKernelGGL(k_restir_raygen, dim3(gridBlk), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, apronBlocks, sp.rays,
+                           sp.deferCount, sp.deferList);
+        if ((rc = launchWalk(c, sp.rays, slots, sp.hits, nullptr, count, defer ? sp.deferCount : nullptr, sp.deferList))) return rc;
+        const int nLights = c->ds.lightSamplerLength - (c->ds.envSamplerLength != 0 ? 1 : 0);
+        const size_t ldsBytes = (size_t)nLights * sizeof(LightPre) + (size_t)c->ds.lightSamplerLength * sizeof(AliasRec);
+        const bool staged = nLights > 0 && ldsBytes <= kRisLdsBytes;
+        if (c->risGrid == 0) {
+            int cus = 0;
+            HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            c->risGrid = (unsigned)(2 * cus);  // two 512-thread workgroups per CU (74 KB of LDS each at 1 026 lights)
+        }
+        const unsigned wgNeeded = (nBlocks1 + (kRisThreads / 64) - 1) / (kRisThreads / 64);
+        const unsigned risGrid = wgNeeded < c->risGrid ? wgNeeded : c->risGrid;
+        if (staged)
+            hipLaunchKernelGGL(k_restir_ris<true>, dim3(risGrid), dim3(kRisThreads), ldsBytes, c->stream, c->ds, c->cam, pm, looper, a, apronBlocks, sp);
+        else
+            hipLaunchKernelGGL(k_restir_ris<false>, dim3(risGrid), dim3(kRisThreads), 0, c->stream, c->ds, c->cam, pm, looper, a, apronBlocks, sp);
+        if ((rc = launchWalk(c, sp.segs, slots, nullptr, sp.occ, count, defer ? sp.deferCount + 1 : nullptr, sp.deferList + kRestirDeferCap)))
+            return rc;
+        hipLaunchKernelGGL(k_restir_resolve, dim3(gridBlk), dim3(256), 0, c->stream, c->ds, pm, iter, a, apronBlocks, sp, d_direct);
+    }
     if (p->reuseMask & 2)
         hipLaunchKernelGGL(k_restir_pass2, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, pm, iter, a, d_direct);
     rc = timeEnd(c, "ReSTIR Direct");
@@ -1123,26 +1242,9 @@ static int walkPersistent(rdh_ctx *c, const float *d_rays, int64_t n, int4 *d_hi
         else hipLaunchKernelGGL((k_trace_wg<false, false>), dim3(g), dim3(kWgTraceThreads), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ);
         return timeEnd(c, what);
     }
-    if (c->walkGrid[any] == 0) {
-        int perCU = 0, cus = 0;
-        if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, true>), 64, 0));
-        else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, false>), 64, 0));
-        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        c->walkGrid[any] = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
-    }
-    const unsigned long long chunks = (unsigned long long)((n + 63) / 64);
-    const unsigned grid = chunks < c->walkGrid[any] ? (unsigned)chunks : c->walkGrid[any];
     timeBegin(c);
-    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
-    const bool count = (flags & RDH_PT_COUNT) != 0;
-    if (any && count)
-        hipLaunchKernelGGL((k_walk_persistent<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ, c->dPersist);
-    else if (any)
-        hipLaunchKernelGGL((k_walk_persistent<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ, c->dPersist);
-    else if (count)
-        hipLaunchKernelGGL((k_walk_persistent<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ, c->dPersist);
-    else
-        hipLaunchKernelGGL((k_walk_persistent<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, (long long)n, d_hits, d_occ, c->dPersist);
+    int rc = launchWalk(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0);
+    if (rc) return rc;
     return timeEnd(c, what);
 }
 }

@@ -5,9 +5,11 @@ spatial), G-buffer + two ReSTIR passes per frame.  Prints one JSON line per spat
 
 One GPU:   python scripts/bench_restir.py
 N GPUs:    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/bench_restir.py
-           one rank per GPU; the frame is cut into 64x64 tiles (tile t -> rank t % N).  Every rank renders the whole G-buffer,
-           shades its tiles (pass 1 on the tiles + an 8-px apron, pass 2 on the tiles), then ONE all-gather of the packed
-           image tiles and ONE of the packed reservoirs (next frame's temporal reuse) per frame over RCCL.
+           one rank per GPU; the frame is cut into 64x64 tiles (tile t -> rank t % N).  Every rank renders the G-buffer records
+           of ITS tiles and the planes are completed by ONE all-gather of 36 B per pixel (RADISH_GBUFFER_REPLICATED=1: every
+           rank renders the whole frame instead, no exchange); it shades its tiles (pass 1 on the tiles + an 8-px apron, pass 2
+           on the tiles), then ONE all-gather of the packed image tiles and ONE of the packed reservoirs (next frame's temporal
+           reuse) per frame over RCCL.  RADISH_RESTIR_FUSED=1 times round 1's fused pass-1 kernel instead of the split one.
            (RADISH_DIST_BACKEND=gloo RADISH_FORCE_DEVICE=0 rehearses N ranks on one GPU.)"""
 import json, os, sys, time
 import numpy as np, torch
@@ -38,6 +40,8 @@ ctx.set_camera(cam)
 ctx.set_partition(rank, world, TILE)
 dev = api.DevScene(); dev.ctx = ctx
 n_local = W * H if world == 1 else ctx.tiles_per_rank() * TILE * TILE
+RESTIR_FLAGS = api.RDH_PT_RESTIR_FUSED if os.environ.get("RADISH_RESTIR_FUSED") == "1" else 0
+GB_PARTITION = world > 1 and os.environ.get("RADISH_GBUFFER_REPLICATED") != "1"
 
 
 def gather(t):
@@ -53,11 +57,18 @@ for nsp in (5, 4):
     img = torch.zeros(n_local, 3, device=dev_t)
     frame_img = torch.zeros(W * H, 3, device=dev_t)
     packed_resv = torch.zeros(n_local, 9, device=dev_t)
+    packed_gb = torch.zeros(n_local, 9, device=dev_t)
     ctx.restir_init()
     def frame(f, flags=0):
-        gb.render(dev, cam)  # blocking, like the reference; the WHOLE frame on every rank
+        ctx.set_camera(cam)
+        ctx.gbuffer_render(gb.c_struct(cam_fallback=cam), api.RDH_PT_PARTITION_GBUFFER if GB_PARTITION else 0)
+        ctx.synchronize()  # blocking, like the reference's GBuffer::render
         t_g = ctx.last_kernel_ms()
-        ctx.restir_direct(img, 0, f, gb.c_struct(cam), 3, num_spatial=nsp, flags=flags)
+        if GB_PARTITION:
+            ctx.gbuffer_exchange_pack(gb.c_struct(cam_fallback=cam), packed_gb)
+            ctx.synchronize()
+            ctx.gbuffer_exchange_unpack(gb.c_struct(cam_fallback=cam), gather(packed_gb))
+        ctx.restir_direct(img, 0, f, gb.c_struct(cam), 3, num_spatial=nsp, flags=flags | RESTIR_FLAGS)
         ctx.synchronize()
         t_r = ctx.last_kernel_ms()
         if world > 1:
@@ -95,7 +106,7 @@ for nsp in (5, 4):
     if rank == 0:
         alg = 40 * c["closestRays"] + 28 * c["anyRays"] + 32 * c["nodeVisits"] + 36 * c["triTests"] + 64 * c["closestHits"] + 2384 * W * H
         print(json.dumps({"config": f"teapots + 1024 emissive tris, {W}x{H}, ReSTIR DI M=32 temporal+spatial", "n_gpus": world, "spatial_neighbours": nsp,
-                          "faithful_ris": 1, "tris": sd.num_prims, "lights": sd.num_lights, "ms_frame_wall": round(el / K * 1e3, 3),
+                          "faithful_ris": 1, "pass1": "fused" if RESTIR_FLAGS else "split", "gbuffer": "partitioned + all-gather" if GB_PARTITION else "whole frame per rank", "tris": sd.num_prims, "lights": sd.num_lights, "ms_frame_wall": round(el / K * 1e3, 3),
                           "ms_gbuffer_kernel": round(tg / K, 3), "ms_restir_kernels": round(tr / K, 3), "rays_per_frame": rays,
                           "mrays_s": round(rays / (el / K) / 1e6, 1),
                           "algorithmic_GBps_restir_rank0": round(alg / (tr / K * 1e-3) / 1e9, 1),

@@ -256,3 +256,59 @@ def test_config5_scene_restir_vs_oracle(gpu_ctx, teasets_1m):
         gb_ref.update(cam)
         gb.update(cam)
     gpu_ctx.restir_free()
+
+
+@pytest.mark.parametrize("reuse", [3, 0])
+def test_config4_restir_1080p_split_equals_fused(gpu_ctx, reuse):
+    """BASELINE config 4 at full size (teapots + 1 024 emissive triangles, 1920x1080, M = 32): the split pass 1 (raygen / walk /
+    RIS from the LDS light table / walk / resolve — the default) and round 1's fused one-lane-per-pixel kernel write identical
+    images and reservoirs over three frames with a moving camera, and count identical work."""
+    from radish_pt_amd import api, hostlib, scenes
+
+    torch = _torch()
+    sd = scenes.teapots(emissive_grid=(16, 32))
+    W, H = 1920, 1080
+    n = W * H
+    cams = [hostlib.make_camera(W, H, eye=(0.3 + 0.02 * f, 1.9, 7.4), rotation=(-91.5, -11.0, 0.0), fovy=19.0) for f in range(3)]
+    gpu_ctx.set_partition(0, 1, 64)
+    gpu_ctx.upload_scene(sd)
+    gpu_ctx.set_camera(cams[0])
+    other, third = api.Context(0), api.Context(0)
+    for c in (other, third):
+        c.upload_scene(sd)
+        c.set_camera(cams[0])
+    gb = api.GBuffer()
+    gb.create(W, H)
+    dev = api.DevScene()
+    dev.ctx = gpu_ctx
+    img_a, img_b, img_c = (torch.zeros(n, 3, device="cuda") for _ in range(3))
+    gpu_ctx.restir_init()
+    other.restir_init()
+    third.restir_init()
+    try:
+        for f, cam in enumerate(cams):
+            gb.render(dev, cam)
+            other.set_camera(cam)
+            gpu_ctx.counters_reset()
+            other.counters_reset()
+            gpu_ctx.restir_direct(img_a, 0, 60 + f, gb.c_struct(cam), reuse, flags=api.RDH_PT_COUNT)
+            other.restir_direct(img_b, 0, 60 + f, gb.c_struct(cam), reuse, flags=api.RDH_PT_COUNT | api.RDH_PT_RESTIR_FUSED)
+            # the split pass with its literal-class rays traced in place by the walker instead of one per workgroup
+            third.set_camera(cam)
+            third.counters_reset()
+            third.restir_direct(img_c, 0, 60 + f, gb.c_struct(cam), reuse, flags=api.RDH_PT_COUNT | api.RDH_PT_NO_DEFER)
+            gpu_ctx.synchronize()
+            other.synchronize()
+            third.synchronize()
+            assert_bit_equal(img_c.cpu().numpy(), img_b.cpu().numpy(), f"split (no defer) vs fused, frame {f}, reuse {reuse}")
+            assert third.counters() == other.counters()
+            assert_bit_equal(img_a.cpu().numpy(), img_b.cpu().numpy(), f"split vs fused, frame {f}, reuse {reuse}")
+            assert gpu_ctx.restir_read(1).tobytes() == other.restir_read(1).tobytes(), f"reservoirs, frame {f}"
+            ca, cb = gpu_ctx.counters(), other.counters()
+            assert ca == cb and ca["closestRays"] == n and ca["anyRays"] > 0.3 * n, (ca, cb)
+            gb.update(cam)
+        assert float(img_a.mean()) > 0.05
+    finally:
+        gpu_ctx.restir_free()
+        other.close()
+        third.close()
