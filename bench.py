@@ -70,7 +70,8 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "persistent"),
-                    choices=["mega", "wavefront", "wavefront_sort", "persistent"])
+                    choices=["mega", "wavefront", "wavefront_sort", "wavefront2", "wavefront_sort2", "persistent"],
+                    help="wavefront2 / wavefront_sort2: the wavefront pipeline as two sub-frames on two streams (RDH_PT_WF_SUBFRAMES)")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_small", "teapots", "teapots_lights", "teasets_1m"])
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,6 +140,8 @@ def main():
     cam = scenes.cornell_camera(W, H) if args.scene.startswith("cornell") else scenes.teapots_camera(W, H)
     flags = {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
              "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,
+             "wavefront2": api.RDH_PT_WAVEFRONT | api.RDH_PT_WF_SUBFRAMES,
+             "wavefront_sort2": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES,
              "persistent": api.RDH_PT_PERSISTENT}[args.mode]
     K, Wm = args.steps, args.warmup
 
@@ -263,6 +266,7 @@ def main():
         launches = max(trace_launches, 1)
         alg_bytes = algorithmic_bytes(counters)  # rank 0's launches
         # per-launch figures only mean something when launches do not overlap (F = 1)
+        # (… and the two-pipeline wavefront modes are not profiled per launch: their launches overlap by design)
         achieved = (alg_bytes / launches) / (trace_ms / launches * 1e-3) / 1e9 if (trace_ms > 0 and F == 1) else None
         traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")

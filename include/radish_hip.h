@@ -90,7 +90,7 @@ typedef struct rdh_counters {
 /* rdh_path_trace flags */
 #define RDH_PT_MEGAKERNEL 0u   /* one lane per pixel, whole path in one launch (the reference's structure)  */
 #define RDH_PT_WAVEFRONT 1u    /* raygen / extend / shade / connect queues with wave64 ballot compaction    */
-#define RDH_PT_SORT_MATERIAL 2u/* wavefront only: bin hits by BSDF type before shading                      */
+#define RDH_PT_SORT_MATERIAL 2u/* wavefront only: each wave bins the 1 024 hit records of its packet by BSDF type before shading them */
 #define RDH_PT_COUNT 4u        /* maintain rdh_counters (adds atomics; leave off when timing)               */
 #define RDH_PT_PERSISTENT 16u  /* one persistent launch: per-lane state machine with lane refill (kernels_persist.h) */
 #define RDH_PT_ONE_LANE_PER_PIXEL 64u /* rdh_gbuffer_render: the one-lane-per-pixel kernel (k_gbuffer) instead of the persistent
@@ -102,6 +102,8 @@ typedef struct rdh_counters {
                                   instead of setting them aside for the workgroup-per-ray launch (k_gbuffer_literal)   */
 #define RDH_PT_PARTITION_GBUFFER 512u /* rdh_gbuffer_render on a tile partition: render the records of THIS rank's tiles only
                                   (complete the planes with rdh_gbuffer_exchange*); default: every rank renders the whole frame */
+#define RDH_PT_WF_SUBFRAMES 2048u /* wavefront only: two sub-frames (interleaved 8x8 blocks) as two pipelines on two streams, so that
+                                  one pipeline's stage tails overlap the other's stage bodies (frames of >= 2 048 blocks) */
 #define RDH_PT_RESTIR_FUSED 1024u /* rdh_restir_direct: round 1's pass 1, one lane per pixel with both walks inside the kernel
                                   (k_restir_pass1), instead of raygen / walk / RIS / walk / resolve (default; same results) */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */

@@ -35,6 +35,7 @@ RDH_PT_NO_DEFER = 128
 RDH_PT_WG_PER_RAY = 256
 RDH_PT_PARTITION_GBUFFER = 512
 RDH_PT_RESTIR_FUSED = 1024
+RDH_PT_WF_SUBFRAMES = 2048
 SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12
 
 # Every symbol include/radish_hip.h declares (tests check that the library exports all of them).

@@ -9,6 +9,7 @@
 //   * all arithmetic is the same device functions the megakernel calls.
 //
 // Launch structure per frame (maxDepth = D):  memset(counters) · raygen · for k = 0..D { trace(k) · shade(k) } · finish
+// (optionally as two sub-frames on two streams, see k_wf_raygen; the material sort happens inside shade, see k_wf_shade)
 //   trace(k)  = any-hit for the shadow rays emitted by shade(k-1)  +  closest-hit for the rays of bounce k
 //   shade(k)  = surface fetch for hit k, emitter/miss termination, then bounce body k+1 (NEE sample → shadow
 //               queue, BSDF sample → next ray queue) with wave64 ballot compaction
@@ -31,7 +32,6 @@ struct alignas(128) WaveCounter {
 struct WaveCounters {
     WaveCounter rayCount[kMaxWaveDepth + 2];     // rays of bounce k (written by raygen / shade(k-1))
     WaveCounter shadowCount[kMaxWaveDepth + 2];  // shadow rays emitted by shade(k)
-    WaveCounter hitCount[kMaxWaveDepth + 2][4];  // hit records of bounce k per shading class
     WaveCounter traceHead[kMaxWaveDepth + 2];
     WaveCounter shadeHead[kMaxWaveDepth + 2][4];
 };
@@ -46,10 +46,9 @@ struct WaveWorkspace {
     float4 *nee;      // pending NEE contribution.xyz, w: 0 → direct, 1 → indirect, -1 → nothing to add
     float4 *sht;      // shadow-ray target.xyz
     uint2 *rng;       // {scramble, ptr}
-    int4 *hit;        // {primId, bary.x, bary.y, dist}
+    int4 *hit;        // {primId, bary.x, bary.y, shading class of the hit's material}
     int *rayq[2];
     int *shadowq;
-    int *hitq[4];
     WaveCounters *ctr;
 };
 
@@ -102,14 +101,20 @@ RD_DEV int wavePull(int *head, int packet = kPacket) {
 }
 
 // ---- raygen ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelMap pm, WaveWorkspace w, int looper) {
+// Sub-frames: the wavefront pipeline can run as H independent pipelines over interleaved block sets (block b belongs to
+// sub-frame b % H), each with its own workspace and stream, so that one sub-frame's stage tails are filled by the other's
+// stage bodies.  `part` / `parts` = h / H; path slots are local to the sub-frame.
+RD_DEV unsigned subFrameBlocks(const PixelMap &pm, int part, int parts) { return (unsigned)(pm.numBlocks - part + parts - 1) / (unsigned)parts; }
+__global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelMap pm, WaveWorkspace w, int looper, int part, int parts) {
     unsigned wg;
-    bool wgValid = xcdSwizzle(blockIdx.x, (unsigned)(pm.numBlocks + 3) >> 2, wg);
+    const unsigned nLocal = subFrameBlocks(pm, part, parts);
+    bool wgValid = xcdSwizzle(blockIdx.x, (nLocal + 3u) >> 2, wg);
     unsigned lane = threadIdx.x & 63u;
-    unsigned block = wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u;
-    Pix px = mapPixel(pm, block, lane);
-    bool valid = px.valid && wgValid;
-    int p = int(block * 64u + lane);  // path slot = work index (fixed for the frame)
+    unsigned blockLocal = wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u;
+    const bool inRange = wgValid && blockLocal < nLocal;
+    Pix px = mapPixel(pm, inRange ? blockLocal * (unsigned)parts + (unsigned)part : 0xffffffffu / 64u, lane);
+    bool valid = px.valid && inRange;
+    int p = int(blockLocal * 64u + lane);  // path slot = work index (fixed for the frame)
     if (valid) {
         Sampler rng = makeSeededRandomEngine(looper, px.index, 0, s.sobol);
         Ray ray = cameraSample(cam, px.x, px.y, sample4D(rng));
@@ -121,8 +126,8 @@ __global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelM
     }
     // Bounce 0's queue is the identity over this launch's slots (-1 marks pixels outside the frame): no compaction,
     // no atomic.
-    if (block < (unsigned)pm.numBlocks) w.rayq[0][p] = valid ? p : -1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.ctr->rayCount[0].v = pm.numBlocks * 64;
+    if (inRange) w.rayq[0][p] = valid ? p : -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.ctr->rayCount[0].v = int(nLocal) * 64;
 }
 
 // ---- trace(k): shadow rays of bounce k (from shade(k-1)) + closest hits of bounce k ---------------------------
@@ -314,8 +319,9 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
             } else {
                 bool hit = hitPrim != -1;
                 if (hit) nHits++;
+                // .w: the shading class of the hit (shade(k)'s material sort bins by it); the distance is not needed again
                 w.hit[p] = make_int4(hitPrim, __float_as_int(hit ? hitBary.x : 0.f), __float_as_int(hit ? hitBary.y : 0.f),
-                                     __float_as_int(tmax));
+                                     hit ? int(s.primClass[hitPrim]) : 0);
             }
             p = -1;
         }
@@ -323,68 +329,25 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
     if (COUNT) flushCounters(s.counters, nClosest, nAny, nHits, ws);
 }
 
-// ---- classify(k) (material sort only): bin bounce k's hit records by BSDF type ------------------------------------
-// Four queues: 0 = terminal (miss / emitter / unknown), 1 = Lambertian, 2 = metallic workflow, 3 = dielectric.
-// One ballot per 64 records and class, one atomic per wave per non-empty class per 256 records.
-__global__ __launch_bounds__(256) void k_wf_classify(DScene s, WaveWorkspace w, int k) {
-    WaveCounters *c = w.ctr;
-    const int n = c->rayCount[k].v;
-    const int *rayq = w.rayq[k & 1];
-    const int lane = int(threadIdx.x & 63u);
-    // four chunks of 64 records per wave and round: their dependent reads (queue -> hit -> triangle -> material) are in flight
-    // together, and each class costs ONE returning atomic per 256 records (they serialise chip-wide per counter)
-    constexpr int C = 4;
-    const int stride = gridWaves() * 64 * C;
-    for (int i0 = globalWave() * 64 * C; i0 < n; i0 += stride) {
-        int p[C], cls[C];
-#pragma unroll
-        for (int j = 0; j < C; j++) {
-            const int i = i0 + j * 64 + lane;
-            p[j] = (i < n) ? rayq[i] : -1;
-        }
-#pragma unroll
-        for (int j = 0; j < C; j++) {
-            cls[j] = -1;
-            if (p[j] >= 0) {
-                int prim = w.hit[p[j]].x;
-                cls[j] = 0;
-                if (prim != -1) {
-                    int matId = __float_as_int(s.tris[prim].c.y);
-                    int type = __float_as_int(s.mats[matId].a.x);
-                    cls[j] = (type == Lambertian) ? 1 : (type == MetallicWorkflow ? 2 : (type == Dielectric ? 3 : 0));
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            unsigned long long m[C];
-            int total = 0;
-#pragma unroll
-            for (int j = 0; j < C; j++) {
-                m[j] = __ballot(cls[j] == q);
-                total += __popcll(m[j]);
-            }
-            if (total == 0) continue;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&c->hitCount[k][q].v, total);
-            base = __shfl(base, 0, 64);
-#pragma unroll
-            for (int j = 0; j < C; j++) {
-                if (cls[j] == q) w.hitq[q][base + __popcll(m[j] & laneMaskLt())] = p[j];
-                base += __popcll(m[j]);
-            }
-        }
-    }
-}
-
 // ---- shade(k): hit k → terminate or run bounce body k+1 ----------------------------------------------------------
-// sorted != 0: drain the four class queues one after the other; else walk bounce k's ray queue as it is.
+// sorted != 0 (material sort, BASELINE config 3): the wave bins the 1 024 records of its packet by BSDF class BEFORE it
+// shades them — class of every record (trace(k) left it in the hit record: one gather), a counting
+// sort by ballots into a 4-KB LDS table of the wave, then the 16 chunks are shaded in class order: at most three of the
+// sixteen chunks straddle a class boundary, the others run one branch of the material switch.  Round 1 had a separate pass over
+// the hit records for this (k_wf_classify: four global class queues, 0.2 ms per bounce on the teapots frame — the sorted
+// pipeline was 1.8 ms SLOWER than the unsorted one); the binning now costs no launch, no global queue and no extra read of the
+// hit records.  Classes: 0 = terminal (miss / emitter / other), 1 = Lambertian, 2 = metallic workflow, 3 = dielectric.
+constexpr int kSortChunks = 16;                  // chunks of 64 records per sorted packet
+constexpr int kSortPacket = 64 * kSortChunks;    // records a wave bins at a time
 __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int k, int maxDepth, int sorted) {
+    __shared__ int sSorted[4][kSortPacket];  // per wave of the workgroup: the packet's path slots in class order
     WaveCounters *c = w.ctr;
     const int lane = int(threadIdx.x & 63u);
-    for (int q = 0; q < (sorted ? 4 : 1); q++) {
-        const int n = sorted ? c->hitCount[k][q].v : c->rayCount[k].v;
-        const int *hitq = sorted ? w.hitq[q] : w.rayq[k & 1];
+    int *mySorted = sSorted[threadIdx.x >> 6];
+    {
+        const int q = 0;
+        const int n = c->rayCount[k].v;
+        const int *hitq = w.rayq[k & 1];
         // queue entries of the packet's chunks, held until its last chunk has been shaded, then appended together
         int pendP[kShadeChunks];
         bool pendShadow[kShadeChunks], pendRay[kShadeChunks];
@@ -393,19 +356,59 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
             pendP[j] = -1;
             pendShadow[j] = pendRay[j] = false;
         }
-        for (int base = globalWave() * kShadePacket, sub = 0;;) {
-            if (sub == kShadePacket) {
-                base = wavePull(&c->shadeHead[k][q].v, kShadePacket);
+        // unsorted: packets of kShadePacket = 256 records.  sorted: 256 .. kSortPacket = 1 024 records (multiples of 256), as large
+        // as still leaves every wave about two packets — with one big packet per wave there is no dynamic balancing left and a
+        // short queue (the Cornell frame after bounce 1) would keep nine waves in ten idle while the others shade 16 chunks each
+        int packet = kShadePacket;
+        if (sorted) {
+            const int perWave = n / (2 * gridWaves());
+            packet = ((perWave + kShadePacket - 1) / kShadePacket) * kShadePacket;
+            packet = packet < kShadePacket ? kShadePacket : (packet > kSortPacket ? kSortPacket : packet);
+        }
+        int packetEnd = 0;  // sorted: records of the current packet that exist (<= kSortPacket)
+        for (int base = globalWave() * packet, sub = 0, fresh = 1;;) {
+            if (sub == packet) {
+                base = wavePull(&c->shadeHead[k][q].v, packet);
                 sub = 0;
+                fresh = 1;
             }
             if (base + sub >= n) break;
+            if (sorted && fresh) {  // bin this packet: counting sort of up to 1 024 records by class
+                fresh = 0;
+                packetEnd = (n - base) < packet ? (n - base) : packet;
+                int pp[kSortChunks], cls[kSortChunks];
+#pragma unroll
+                for (int j = 0; j < kSortChunks; j++) {
+                    const int i = base + j * 64 + lane;
+                    pp[j] = (j * 64 + lane < packetEnd) ? hitq[i] : -1;
+                }
+#pragma unroll
+                for (int j = 0; j < kSortChunks; j++) {
+                    // class of the hit, as trace(k) recorded it; off-frame slots of bounce 0 (p = -1) sort with the terminal
+                    // class and are skipped below
+                    cls[j] = (pp[j] >= 0) ? w.hit[pp[j]].w : 0;
+                }
+                int at = 0;  // running position in class order (wave-uniform)
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+#pragma unroll
+                    for (int j = 0; j < kSortChunks; j++) {
+                        const bool in = (j * 64 + lane < packetEnd) && cls[j] == qq;
+                        const unsigned long long m = __ballot(in);
+                        if (in) mySorted[at + __popcll(m & laneMaskLt())] = pp[j];
+                        at += __popcll(m);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();  // one wave writes and then reads its own table: LDS executes a wave's ops in order
+            }
             int item = base + sub + lane;
+            const int subNow = sub;
             sub += 64;
-            bool active = item < n;
+            bool active = sorted ? (subNow + lane < packetEnd) : (item < n);
             bool emitShadow = false, emitRay = false;
             int p = -1;
             if (active) {
-                p = hitq[item];
+                p = sorted ? mySorted[subNow + lane] : hitq[item];
                 active = p >= 0;
             }
             if (active) {
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                 } while (false);
             }
             {
-                const int j = (sub >> 6) - 1;  // chunk just shaded (wave-uniform)
+                const int j = ((sub >> 6) - 1) & (kShadeChunks - 1);  // chunk just shaded, within its group of four (wave-uniform)
 #pragma unroll
                 for (int jj = 0; jj < kShadeChunks; jj++)
                     if (jj == j) {
@@ -508,7 +511,8 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                         pendRay[jj] = emitRay;
                     }
             }
-            if (sub == kShadePacket || base + sub >= n) {  // last chunk of the packet (the loop leaves or pulls next): append
+            // every fourth chunk, and at the last chunk of the queue (the loop then leaves or pulls the next packet): append
+            if ((sub & (kShadePacket - 1)) == 0 || base + sub >= n) {
                 waveAppendN(pendShadow, pendP, w.shadowq, &c->shadowCount[k].v);
                 waveAppendN(pendRay, pendP, w.rayq[(k + 1) & 1], &c->rayCount[k + 1].v);
 #pragma unroll
@@ -520,14 +524,16 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
 
 // ---- finish: NaN scrub, HDRToLDR, running mean (pathtrace.cu:279-290) ------------------------------------------
 __global__ __launch_bounds__(256) void k_wf_finish(PixelMap pm, WaveWorkspace w, int iter, float *__restrict__ directIllum,
-                                                   float *__restrict__ indirectIllum) {
+                                                   float *__restrict__ indirectIllum, int part, int parts) {
     unsigned wg;
-    bool wgValid = xcdSwizzle(blockIdx.x, (unsigned)(pm.numBlocks + 3) >> 2, wg);
+    const unsigned nLocal = subFrameBlocks(pm, part, parts);
+    bool wgValid = xcdSwizzle(blockIdx.x, (nLocal + 3u) >> 2, wg);
     unsigned lane = threadIdx.x & 63u;
-    unsigned block = wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u;
-    Pix px = mapPixel(pm, block, lane);
-    if (!(px.valid && wgValid)) return;
-    int p = int(block * 64u + lane);
+    unsigned blockLocal = wgValid ? wg * 4u + (threadIdx.x >> 6) : 0xffffffffu / 64u;
+    const bool inRange = wgValid && blockLocal < nLocal;
+    Pix px = mapPixel(pm, inRange ? blockLocal * (unsigned)parts + (unsigned)part : 0xffffffffu / 64u, lane);
+    if (!(px.valid && inRange)) return;
+    int p = int(blockLocal * 64u + lane);
     float4 a = w.accD[p], b = w.accI[p];
     v3 direct = mk3(a.x, a.y, a.z), indirect = mk3(b.x, b.y, b.z);
     if (hasNanOrInf(direct)) direct = mk3(0.f);

@@ -73,6 +73,8 @@ struct DScene {
     const TriRec *tris;
     const AttrRec *attrs;
     const MatRec *mats;
+    const unsigned char *primClass;  // per triangle: shading class of its material (0 terminal / other, 1 Lambertian, 2 metallic
+                                     // workflow, 3 dielectric) — what the wavefront pipeline's material sort bins by
     const LightRec *lights;
     const LightPre *lightPre;  // numLights records (no entry for the environment map)
     const AliasRec *lightAlias;

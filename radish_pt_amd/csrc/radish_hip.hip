@@ -45,7 +45,7 @@ struct rdh_ctx {
     unsigned persistGrid = 0;
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
-    unsigned wfGrid[4] = {0, 0, 0, 0};  // resident workgroups of k_wf_trace<false> / <true>, k_wf_classify, k_wf_shade
+    unsigned wfGrid[4] = {0, 0, 0, 0};  // resident workgroups of k_wf_trace<false> / <true>, (unused), k_wf_shade
     float *posPlane = nullptr;  // denoisers: Camera::getPosition of every pixel (k_position_plane)
     long long posPlanePixels = 0;
     // Longest-paths-first block order (k_persist_schedule), off the critical path: launch n writes blockCost[n & 1]; the
@@ -91,9 +91,10 @@ struct rdh_ctx {
     size_t commSendFloats[2] = {0, 0}, commRecvFloats = 0;
 
     // wavefront workspace
-    WaveWorkspace wf{};
-    long long wfCapacity = 0;
+    WaveWorkspace wf[2] = {};  // one per sub-frame (RDH_PT_WF_SUBFRAMES: two pipelines on two streams)
+    long long wfCapacity = 0;   // path slots each workspace holds
     std::vector<void *> wfAllocs;
+    hipEvent_t evWfFork = nullptr, evWfJoin = nullptr;
 };
 
 namespace {
@@ -225,23 +226,29 @@ int wfAlloc(rdh_ctx *c, T **out, size_t count) {
     return RDH_OK;
 }
 
-// Workspace for the wavefront pipeline: 152 B of path state + 7 queue slots per path slot.
+// Workspace for the wavefront pipeline: 152 B of path state + 3 queue slots per path slot, per sub-frame.
 int wavefrontEnsure(rdh_ctx *c, const PixelMap &pm) {
-    long long slots = (long long)pm.numBlocks * 64;
+    long long slots = (long long)pm.numBlocks * 64;  // a sub-frame of two holds at most half (+ one block)
     if (c->wfCapacity >= slots) return RDH_OK;
     for (void *p : c->wfAllocs) hipFree(p);
     c->wfAllocs.clear();
     c->wfCapacity = 0;
-    WaveWorkspace &w = c->wf;
-    int rc;
-    size_t n = (size_t)slots;
-    if ((rc = wfAlloc(c, &w.ro, n)) || (rc = wfAlloc(c, &w.rd, n)) || (rc = wfAlloc(c, &w.thr, n)) ||
-        (rc = wfAlloc(c, &w.prevPos, n)) || (rc = wfAlloc(c, &w.accD, n)) || (rc = wfAlloc(c, &w.accI, n)) ||
-        (rc = wfAlloc(c, &w.nee, n)) || (rc = wfAlloc(c, &w.sht, n)) || (rc = wfAlloc(c, &w.rng, n)) ||
-        (rc = wfAlloc(c, &w.hit, n)) || (rc = wfAlloc(c, &w.rayq[0], n)) || (rc = wfAlloc(c, &w.rayq[1], n)) ||
-        (rc = wfAlloc(c, &w.shadowq, n)) || (rc = wfAlloc(c, &w.hitq[0], n)) || (rc = wfAlloc(c, &w.hitq[1], n)) ||
-        (rc = wfAlloc(c, &w.hitq[2], n)) || (rc = wfAlloc(c, &w.hitq[3], n)) || (rc = wfAlloc(c, &w.ctr, 1)))
-        return rc;
+    const size_t n0 = (size_t)slots, n1 = (size_t)((pm.numBlocks + 1) / 2) * 64;
+    for (int h = 0; h < 2; h++) {
+        WaveWorkspace &w = c->wf[h];
+        const size_t n = h == 0 ? n0 : n1;  // workspace 0 also serves the one-pipeline mode (whole frame)
+        int rc;
+        if ((rc = wfAlloc(c, &w.ro, n)) || (rc = wfAlloc(c, &w.rd, n)) || (rc = wfAlloc(c, &w.thr, n)) ||
+            (rc = wfAlloc(c, &w.prevPos, n)) || (rc = wfAlloc(c, &w.accD, n)) || (rc = wfAlloc(c, &w.accI, n)) ||
+            (rc = wfAlloc(c, &w.nee, n)) || (rc = wfAlloc(c, &w.sht, n)) || (rc = wfAlloc(c, &w.rng, n)) ||
+            (rc = wfAlloc(c, &w.hit, n)) || (rc = wfAlloc(c, &w.rayq[0], n)) || (rc = wfAlloc(c, &w.rayq[1], n)) ||
+            (rc = wfAlloc(c, &w.shadowq, n)) || (rc = wfAlloc(c, &w.ctr, 1)))
+            return rc;
+    }
+    if (!c->evWfFork) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->evWfFork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->evWfJoin, hipEventDisableTiming));
+    }
     c->wfCapacity = slots;
     return RDH_OK;
 }
@@ -250,33 +257,56 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
                        int maxDepth, uint32_t flags) {
     if (maxDepth > kMaxWaveDepth) return fail(c, RDH_ERR_ARGS, "maxDepth %d exceeds %d", maxDepth, kMaxWaveDepth);
     const bool count = (flags & RDH_PT_COUNT) != 0, sort = (flags & RDH_PT_SORT_MATERIAL) != 0;
-    WaveWorkspace &w = c->wf;
-    HIP_TRY(c, hipMemsetAsync(w.ctr, 0, sizeof(WaveCounters), c->stream));
-    hipLaunchKernelGGL(k_wf_raygen, dim3(gridFor(pm)), dim3(256), 0, c->stream, c->ds, c->cam, pm, w, looper);
     // Persistent kernels whose waves take a STATIC first packet: every workgroup must be resident from the start, or the
-    // surplus ones run their static packets after everybody else has finished (k_wf_trace fits 6 waves per SIMD, k_wf_shade 4:
-    // the fixed grid of 8 per SIMD used before left a quarter / half of the waves waiting for a slot).
+    // surplus ones run their static packets after everybody else has finished (k_wf_trace fits 6 waves per SIMD, k_wf_shade 3).
     if (c->wfGrid[0] == 0) {
-        int cus = 0, per[4] = {0, 0, 0, 0};
+        int cus = 0, per[4] = {0, 0, 1, 0};
         HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
         HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[0], k_wf_trace<false>, 256, 0));
         HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[1], k_wf_trace<true>, 256, 0));
-        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[2], k_wf_classify, 256, 0));
         HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[3], k_wf_shade, 256, 0));
         for (int q = 0; q < 4; q++) {
             unsigned g = (unsigned)((per[q] < 1 ? 1 : per[q]) * cus);
             c->wfGrid[q] = g < kPersistentGrid ? g : kPersistentGrid;
         }
     }
-    for (int k = 0; k <= maxDepth; k++) {
-        long pe = profBegin(c, flags);
-        if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(c->wfGrid[1]), dim3(256), 0, c->stream, c->ds, w, k);
-        else hipLaunchKernelGGL(k_wf_trace<false>, dim3(c->wfGrid[0]), dim3(256), 0, c->stream, c->ds, w, k);
-        profEnd(c, pe);
-        if (sort) hipLaunchKernelGGL(k_wf_classify, dim3(c->wfGrid[2]), dim3(256), 0, c->stream, c->ds, w, k);
-        hipLaunchKernelGGL(k_wf_shade, dim3(c->wfGrid[3]), dim3(256), 0, c->stream, c->ds, w, k, maxDepth, sort ? 1 : 0);
+    // Two sub-frames (interleaved 8x8 blocks) as two pipelines on two streams: every stage of one pipeline ends on its longest
+    // ray while the other pipeline's stage fills the chip.  Each pipeline launches half-size grids so that the two together are
+    // resident.  Small frames stay one pipeline.
+    const int parts = ((flags & RDH_PT_WF_SUBFRAMES) && pm.numBlocks >= 2048) ? 2 : 1;
+    if (parts == 2) {
+        HIP_TRY(c, hipEventRecord(c->evWfFork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evWfFork, 0));
     }
-    hipLaunchKernelGGL(k_wf_finish, dim3(gridFor(pm)), dim3(256), 0, c->stream, pm, w, iter, d_direct, d_indirect);
+    for (int h = 0; h < parts; h++) {
+        hipStream_t st = h == 0 ? c->stream : c->sideStream;
+        WaveWorkspace &w = c->wf[h];
+        const unsigned nLocal = (unsigned)(pm.numBlocks - h + parts - 1) / (unsigned)parts;
+        const unsigned gridBlk = (((nLocal + 3u) / 4u + 7u) / 8u) * 8u;
+        HIP_TRY(c, hipMemsetAsync(w.ctr, 0, sizeof(WaveCounters), st));
+        hipLaunchKernelGGL(k_wf_raygen, dim3(gridBlk), dim3(256), 0, st, c->ds, c->cam, pm, w, looper, h, parts);
+    }
+    for (int k = 0; k <= maxDepth; k++) {
+        for (int h = 0; h < parts; h++) {  // interleaved issue: stage k of both pipelines before stage k + 1 of either
+            hipStream_t st = h == 0 ? c->stream : c->sideStream;
+            WaveWorkspace &w = c->wf[h];
+            long pe = (h == 0 && parts == 1) ? profBegin(c, flags) : -1;
+            if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(c->wfGrid[1] / parts), dim3(256), 0, st, c->ds, w, k);
+            else hipLaunchKernelGGL(k_wf_trace<false>, dim3(c->wfGrid[0] / parts), dim3(256), 0, st, c->ds, w, k);
+            profEnd(c, pe);
+            hipLaunchKernelGGL(k_wf_shade, dim3(c->wfGrid[3] / parts), dim3(256), 0, st, c->ds, w, k, maxDepth, sort ? 1 : 0);
+        }
+    }
+    for (int h = 0; h < parts; h++) {
+        hipStream_t st = h == 0 ? c->stream : c->sideStream;
+        const unsigned nLocal = (unsigned)(pm.numBlocks - h + parts - 1) / (unsigned)parts;
+        const unsigned gridBlk = (((nLocal + 3u) / 4u + 7u) / 8u) * 8u;
+        hipLaunchKernelGGL(k_wf_finish, dim3(gridBlk), dim3(256), 0, st, pm, c->wf[h], iter, d_direct, d_indirect, h, parts);
+    }
+    if (parts == 2) {
+        HIP_TRY(c, hipEventRecord(c->evWfJoin, c->sideStream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evWfJoin, 0));
+    }
     return RDH_OK;
 }
 
@@ -406,6 +436,8 @@ void rdh_destroy(rdh_ctx *c) {
     }
     if (c->blockEma) hipFree(c->blockEma);
     if (c->evFrame) hipEventDestroy(c->evFrame);
+    if (c->evWfFork) hipEventDestroy(c->evWfFork);
+    if (c->evWfJoin) hipEventDestroy(c->evWfJoin);
     if (c->evStart) hipEventDestroy(c->evStart);
     if (c->evStop) hipEventDestroy(c->evStop);
     if (c->evFork) hipEventDestroy(c->evFork);
@@ -510,6 +542,14 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
     if ((rc = uploadVec(c, tris, &c->ds.tris))) return rc;
     if ((rc = uploadVec(c, attrs, &c->ds.attrs))) return rc;
     if ((rc = uploadVec(c, mats, &c->ds.mats))) return rc;
+    {  // shading class per triangle (Material::Type of its material, src/material.h:129): the key of the wavefront material sort
+        std::vector<unsigned char> cls(N);
+        for (int p = 0; p < N; p++) {
+            const int type = hm[d->materialIds[p]].type;
+            cls[p] = type == 0 ? 1 : (type == 1 ? 2 : (type == 2 ? 3 : 0));  // Lambertian, MetallicWorkflow, Dielectric; else terminal
+        }
+        if ((rc = uploadVec(c, cls, &c->ds.primClass))) return rc;
+    }
     if ((rc = uploadVec(c, texBlob, &c->ds.texData))) return rc;
     if ((rc = uploadVec(c, texInfo, &c->ds.texInfo))) return rc;
     std::vector<AliasRec> envAlias(d->envMapSamplerLength);

@@ -48,7 +48,8 @@ def test_config1_cornell_400x400_depth4_16spp(gpu_ctx, cornell_full):
     gpu_ctx.upload_scene(cornell_full)
     gpu_ctx.set_camera(cam)
     for name, flags in (("persistent", api.RDH_PT_PERSISTENT), ("megakernel", api.RDH_PT_MEGAKERNEL),
-                        ("wavefront+sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL)):
+                        ("wavefront+sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL),
+                        ("wavefront+sort, two sub-frames", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES)):
         d = torch.zeros(W * H, 3, device="cuda")
         i = torch.zeros(W * H, 3, device="cuda")
         gpu_ctx.counters_reset()
@@ -77,13 +78,15 @@ def test_config3_teapots_1080p_wavefront_sort(gpu_ctx):
     gpu_ctx.set_camera(cam)
     out = {}
     for name, flags in (("sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL), ("wave", api.RDH_PT_WAVEFRONT),
+                        ("sort2", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES),
+                        ("wave2", api.RDH_PT_WAVEFRONT | api.RDH_PT_WF_SUBFRAMES),
                         ("persist", api.RDH_PT_PERSISTENT), ("mega", api.RDH_PT_MEGAKERNEL)):
         d = torch.zeros(W * H, 3, device="cuda")
         i = torch.zeros(W * H, 3, device="cuda")
         gpu_ctx.counters_reset()
         gpu_ctx.path_trace(d, i, 0, 3, depth, flags | api.RDH_PT_COUNT)
         out[name] = (d.cpu().numpy(), i.cpu().numpy(), gpu_ctx.counters())
-    for name in ("wave", "persist", "mega"):
+    for name in ("wave", "sort2", "wave2", "persist", "mega"):
         assert_bit_equal(out[name][0], out["sort"][0], f"config 3: {name} vs sorted wavefront, direct")
         assert_bit_equal(out[name][1], out["sort"][1], f"config 3: {name} vs sorted wavefront, indirect")
         assert out[name][2] == out["sort"][2], name
