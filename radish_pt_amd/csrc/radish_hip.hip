@@ -1472,8 +1472,22 @@ int rdh_denoise_eaw(rdh_ctx *c, float *d_colorOut, const float *d_colorIn, const
     HIP_TRY(c, hipSetDevice(c->device));
     rc = denoisePositions(c, d, cam);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_eaw_filter, denoiseGrid(cam.resx, cam.resy), dim3(256), 0, c->stream, d_colorOut, d_colorIn, d, sigDepth,
-                       sigNormal, sigLumin, cam, level);
+    {
+        const dim3 grid = denoiseTileGrid(cam.resx, cam.resy, level);
+        const int v = (sigmaIsPow2(sigLumin) ? 4 : 0) | (sigmaIsPow2(sigNormal) ? 2 : 0) | (sigmaIsPow2(sigDepth) ? 1 : 0);
+#define RD_EAW(L, N, D) hipLaunchKernelGGL((k_eaw_filter<L, N, D>), grid, dim3(256), 0, c->stream, d_colorOut, d_colorIn, d, sigDepth, sigNormal, sigLumin, cam, level)
+        switch (v) {
+            case 0: RD_EAW(false, false, false); break;
+            case 1: RD_EAW(false, false, true); break;
+            case 2: RD_EAW(false, true, false); break;
+            case 3: RD_EAW(false, true, true); break;
+            case 4: RD_EAW(true, false, false); break;
+            case 5: RD_EAW(true, false, true); break;
+            case 6: RD_EAW(true, true, false); break;
+            default: RD_EAW(true, true, true); break;
+        }
+#undef RD_EAW
+    }
     HIP_TRY(c, hipGetLastError());
     return RDH_OK;
 }
@@ -1491,8 +1505,12 @@ int rdh_denoise_svgf(rdh_ctx *c, float *d_colorOut, const float *d_colorIn, floa
     HIP_TRY(c, hipSetDevice(c->device));
     rc = denoisePositions(c, d, cam);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_svgf_filter, denoiseGrid(cam.resx, cam.resy), dim3(256), 0, c->stream, d_colorOut, d_colorIn, d_varianceOut,
-                       d_varianceIn, d_filteredVar, d, sigDepth, sigNormal, sigLumin, cam, level);
+    if (sigmaIsPow2(sigDepth + 1e-4f))
+        hipLaunchKernelGGL((k_svgf_filter<true>), denoiseTileGrid(cam.resx, cam.resy, level), dim3(256), 0, c->stream, d_colorOut, d_colorIn,
+                           d_varianceOut, d_varianceIn, d_filteredVar, d, sigDepth, sigNormal, sigLumin, cam, level);
+    else
+        hipLaunchKernelGGL((k_svgf_filter<false>), denoiseTileGrid(cam.resx, cam.resy, level), dim3(256), 0, c->stream, d_colorOut, d_colorIn,
+                           d_varianceOut, d_varianceIn, d_filteredVar, d, sigDepth, sigNormal, sigLumin, cam, level);
     HIP_TRY(c, hipGetLastError());
     return RDH_OK;
 }

@@ -36,8 +36,8 @@ a = torch.zeros(n, 3, device="cuda"); b = torch.zeros(n, 3, device="cuda")
 var = torch.rand(n, device="cuda"); var2 = torch.zeros(n, device="cuda"); fvar = torch.zeros(n, device="cuda")
 mom = torch.rand(n, 3, device="cuda"); mom2 = torch.zeros(n, 3, device="cuda")
 pbo = torch.zeros(n, dtype=torch.int32, device="cuda")
-for kind, nm in ((0, "float3 image"), (1, "float plane"), (2, "int plane"), (3, "motion")):
-    src = {0: noisy, 1: gb.depth[gb.frameIdx], 2: gb.primId[gb.frameIdx], 3: gb.motion}[kind]
+# kind 0: vec3 image (tone-mapped), kind 2: float plane as grey, kind 3: int pixel indices (the motion view); kind 1 takes vec2 images
+for kind, nm, src in ((0, "float3 image", noisy), (2, "float plane", gb.depth[gb.frameIdx]), (3, "motion", gb.motion)):
     timed(f"copy_image_to_pbo[{nm}]", lambda: ctx.copy_image_to_pbo(pbo, src, W, H, kind, 2 if kind == 0 else 0, 1.0), (12 if kind == 0 else 4) + 4)
 for lv in (0, 2, 4):
     timed(f"eaw_filter[level {lv}]", lambda: ctx.denoise_eaw(a, noisy, gbc, cam, 64.0, 0.2, 1.0, lv), 12 + 12 + 4 + 4 + 12)
