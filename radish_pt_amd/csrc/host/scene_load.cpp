@@ -158,7 +158,12 @@ Image decodePNG(const std::vector<uint8_t> &d, const std::string &name) {
         p += 12 + (size_t)len;
     }
     if (W == 0 || H == 0 || W > 65535 || H > 65535) failf("%s: bad PNG size", name.c_str());
+    if ((uint64_t)W * H > (1ull << 28)) failf("%s: PNG of %u x %u pixels is larger than this loader accepts (2^28)", name.c_str(), W, H);
     if (interlace) failf("%s: interlaced PNG is not supported", name.c_str());
+    // the PNG specification's table of bit depths per colour type: 0 (grey) 1,2,4,8,16; 3 (palette) 1,2,4,8; 2, 4, 6: 8 or 16.
+    // (A depth of 0 used to give a zero stride and an integer division by zero; depths of 3, 5, 6, 7 were decoded silently.)
+    if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) failf("%s: PNG bit depth %d is not one of 1, 2, 4, 8, 16", name.c_str(), depth);
+    if (ctype == 3 && depth == 16) failf("%s: a palette PNG cannot have 16-bit indices", name.c_str());
     if (depth != 8 && depth != 16 && !(ctype == 3 || ctype == 0)) failf("%s: PNG bit depth %d unsupported", name.c_str(), depth);
     int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!channels) failf("%s: PNG colour type %d unsupported", name.c_str(), ctype);

@@ -190,6 +190,37 @@ def test_path_trace_bit_exact(cornell_gpu, cornell_small, flags_name, size, dept
         assert ct[k] == st[k], k
 
 
+def test_dump_rays_reproduces_the_frames_work(cornell_gpu, cornell_small):
+    """rdh_dump_rays (the ray lists behind bench.py's roofline.traversal_only and the CPU traversal denominator): the lists hold
+    exactly the frame's rays — walking them costs the frame's node visits, triangle tests and hits, on the GPU (walk-only kernel)
+    and on the oracle; their hit records and occlusion flags equal the oracle's."""
+    from radish_pt_amd import api, layouts as L, scenes
+
+    torch = _torch()
+    W, H, depth, looper = 96, 64, 5, 12
+    cam = scenes.cornell_camera(W, H)
+    cornell_gpu.set_camera(cam)
+    d, i = torch.zeros(W * H, 3, device="cuda"), torch.zeros(W * H, 3, device="cuda")
+    cornell_gpu.counters_reset()
+    cornell_gpu.path_trace(d, i, 0, looper, depth, api.RDH_PT_PERSISTENT | api.RDH_PT_COUNT)
+    frame = cornell_gpu.counters()
+    closest, segs = cornell_gpu.dump_rays(looper, depth)
+    assert closest.shape[0] == frame["closestRays"] and segs.shape[0] == frame["anyRays"]
+    hits = torch.zeros(closest.shape[0], 4, dtype=torch.int32, device="cuda")
+    occ = torch.zeros(segs.shape[0], dtype=torch.int32, device="cuda")
+    cornell_gpu.counters_reset()
+    cornell_gpu.trace_closest(closest.contiguous(), hits, api.RDH_PT_PERSISTENT | api.RDH_PT_COUNT)
+    cornell_gpu.trace_occluded(segs.contiguous(), occ, api.RDH_PT_PERSISTENT | api.RDH_PT_COUNT)
+    assert cornell_gpu.counters() == frame
+    o = _oracle(cornell_small)
+    ref_h = o.trace_closest(closest.cpu().numpy())
+    ref_o = o.trace_occluded(segs.cpu().numpy())
+    assert o.stats() == frame
+    got = hits.cpu().numpy().view(L.HIT_DTYPE).reshape(-1)
+    assert np.array_equal(got["primId"], ref_h["primId"]) and np.array_equal(occ.cpu().numpy(), ref_o)
+    assert_bit_equal(got["t"], ref_h["t"], "hit.t of the dumped rays")
+
+
 def test_path_trace_depth_zero_and_one(cornell_gpu, cornell_small):
     from radish_pt_amd import api, scenes
 

@@ -289,6 +289,50 @@ def test_parse_errors(tmp_path):
         hostlib.parse_scene(str(tmp_path / "s4.txt"))
 
 
+def _png(width, height, depth, ctype, rows, interlace=0):
+    """A PNG file from raw scanlines (filter byte 0 prepended to each), any header values — including invalid ones."""
+    import struct
+    import zlib
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+
+    raw = b"".join(b"\x00" + bytes(r) for r in rows)
+    return (bytes([137, 80, 78, 71, 13, 10, 26, 10]) + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, ctype, 0, 0, interlace))
+            + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def test_malformed_png_headers_are_rejected(tmp_path):
+    """IHDR bit depths the PNG specification does not allow (depth 0 gave a zero stride and an integer division by
+    zero in the host process, depths 3 / 5 / 6 / 7 were decoded silently), 16-bit palette indices, sub-byte depths on colour
+    types that forbid them, and absurd sizes — each must come back as an error through the C ABI, never as a crash."""
+    scene = "Material m\nType Lambertian\nBaseColor {}\nMetallic 0\nRoughness 1\nIor 1\nNormalMap Null\n\n" \
+            "Object 0\na.obj\nMaterial m\n\nCamera\nResolution 8 8\nFovY 20\nLensRadius 0\nFocalDist 1\nApertureMask Null\n" \
+            "Sample 1\nDepth 2\nFile x\nEye 0 0 3\nRotation -90 0 0\nUp 0 1 0\n\n"
+    (tmp_path / "a.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    bad = {
+        "depth0.png": _png(2, 2, 0, 0, [[0], [0]]),
+        "depth3.png": _png(2, 2, 3, 0, [[0], [0]]),
+        "depth7.png": _png(2, 2, 7, 0, [[0, 0], [0, 0]]),
+        "depth32.png": _png(2, 2, 32, 0, [[0] * 8, [0] * 8]),
+        "pal16.png": _png(2, 2, 16, 3, [[0] * 4, [0] * 4]),
+        "rgb4.png": _png(2, 2, 4, 2, [[0] * 3, [0] * 3]),
+        "huge.png": _png(60000, 60000, 8, 0, [[0]]),
+        "interlaced.png": _png(2, 2, 8, 0, [[0, 0], [0, 0]], interlace=1),
+    }
+    for name, blob in bad.items():
+        (tmp_path / name).write_bytes(blob)
+        (tmp_path / "s.txt").write_text(scene.format(name))
+        with pytest.raises(RuntimeError):
+            hostlib.parse_scene(str(tmp_path / "s.txt"))
+    # and the valid small-depth forms still decode: 1-bit grey, 2 x 2, rows 0b10 / 0b01 -> white black / black white
+    (tmp_path / "ok1.png").write_bytes(_png(2, 2, 1, 0, [[0b10000000], [0b01000000]]))
+    (tmp_path / "s.txt").write_text(scene.format("ok1.png"))
+    ps = hostlib.parse_scene(str(tmp_path / "s.txt"))
+    tex = ps["textures"][0] if isinstance(ps, dict) else ps.textures[0]
+    assert np.asarray(tex).reshape(2, 2, 3)[..., 0].max() > 0
+
+
 def test_hdr_rle_and_pfm(tmp_path):
     rng = np.random.default_rng(5)
     w, h = 16, 3
