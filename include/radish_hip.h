@@ -244,6 +244,11 @@ int rdh_denoise_filter_variance(rdh_ctx *ctx, float *d_varianceOut, const float 
 
 /* Test access to the reservoir buffers (36-byte DirectReservoir[w*h]): which = 0 current out, 1 last, 2 temp. */
 int rdh_restir_read(rdh_ctx *ctx, int which, void *hostOut);
+/* Test / analysis access to what the last split pass 1 (rdh_restir_direct without RDH_PT_RESTIR_FUSED) left between its launches,
+ * per slot of its launch domain: which = 0 primary rays (6 floats), 1 shadow segments (6 floats, NaN first = none),
+ * 2 the set-aside lists {int count[4]; int primarySlots[256]; int shadowSlots[256]}.  Returns the byte size (hostOut NULL: only
+ * that), or a negative RDH_ERR_*. */
+long long rdh_restir_read_scratch(rdh_ctx *ctx, int which, void *hostOut, long long maxBytes);
 
 /* ---- traversal entry points (tests / roofline bench) ------------------------------------------------ */
 /* d_rays: {origin.xyz, direction.xyz}[n].  DevScene::intersect (src/scene.h:262-301) per ray.

@@ -43,7 +43,7 @@ EXPORTS = [
     "rdh_create", "rdh_destroy", "rdh_last_error", "rdh_set_stream", "rdh_synchronize", "rdh_scene_upload",
     "rdh_scene_free", "rdh_set_camera", "rdh_set_partition", "rdh_tiles_per_rank", "rdh_untile", "rdh_path_trace",
     "rdh_path_trace_direct", "rdh_gbuffer_render", "rdh_restir_init", "rdh_restir_free", "rdh_restir_direct",
-    "rdh_restir_read", "rdh_copy_image_to_pbo", "rdh_denoise_eaw", "rdh_denoise_svgf", "rdh_denoise_modulate",
+    "rdh_restir_read", "rdh_restir_read_scratch", "rdh_copy_image_to_pbo", "rdh_denoise_eaw", "rdh_denoise_svgf", "rdh_denoise_modulate",
     "rdh_denoise_add", "rdh_denoise_temporal_accumulate", "rdh_denoise_estimate_variance", "rdh_denoise_filter_variance", "rdh_restir_exchange_pack", "rdh_restir_exchange_unpack", "rdh_trace_closest", "rdh_trace_occluded", "rdh_counters_reset", "rdh_counters_read",
     "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps", "rdh_debug_persist_phases",
     "rdh_gbuffer_exchange_pack", "rdh_gbuffer_exchange_unpack", "rdh_comm_unique_id", "rdh_comm_init", "rdh_comm_destroy",
@@ -123,6 +123,7 @@ def lib():
             "rdh_restir_free": ([vp], i32),
             "rdh_restir_direct": ([vp, vp, i32, i32, C.POINTER(GBufferC), C.POINTER(RestirParamsC), u32], i32),
             "rdh_restir_read": ([vp, i32, vp], i32),
+            "rdh_restir_read_scratch": ([vp, i32, vp, i64], i64),
             "rdh_copy_image_to_pbo": ([vp, vp, vp, i32, i32, i32, i32, C.c_float], i32),
             "rdh_denoise_eaw": ([vp, vp, vp, C.POINTER(GBufferC), vp] + [C.c_float] * 3 + [i32], i32),
             "rdh_denoise_svgf": ([vp, vp, vp, vp, vp, vp, C.POINTER(GBufferC), vp] + [C.c_float] * 3 + [i32], i32),
@@ -407,6 +408,18 @@ class Context:
         out = np.zeros(self.width * self.height, dtype=L.RESERVOIR_DTYPE)
         self.check(lib().rdh_restir_read(self.h, which, out.ctypes.data))
         return out
+
+    def restir_read_scratch(self, which):
+        """What the last split pass 1 left per slot: 0 primary rays [slots, 6], 1 shadow segments [slots, 6], 2 the set-aside
+        lists as int32 {count[4], primarySlots[256], shadowSlots[256]} (rdh_restir_read_scratch)."""
+        nbytes = int(lib().rdh_restir_read_scratch(self.h, which, None, 0))
+        if nbytes < 0:
+            self.check(nbytes)
+        out = np.zeros(nbytes // 4, np.int32 if which == 2 else np.float32)
+        got = int(lib().rdh_restir_read_scratch(self.h, which, out.ctypes.data, nbytes))
+        if got < 0:
+            self.check(got)
+        return out if which == 2 else out.reshape(-1, 6)
 
     def trace_closest(self, rays, hits, flags=RDH_PT_PERSISTENT):  # flags without RDH_PT_PERSISTENT: one lane per ray
         n = rays.numel() // 6  # n == 0 still reaches the library (it returns at once)

@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
                         pending = -1;
                         hitPrim = -1;
                         tmax = 3.402823466e+38f;
-                        if (DEFER && rs.cls != 0 && end != 0 && deferAll) {
+                        if (DEFER && raySetAside(rs.cls) && end != 0 && deferAll) {
                             // a literal-class ray: k_gbuffer_literal has it (found by k_gbuffer_find_literal)
                         } else {
                             nClosest++;
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void k_gbuffer_find_literal(DScene s, DCamera 
     // on a tile partition only the rays of this rank's tiles (tile t belongs to rank t % world)
     if (pm.world > 1 && (((idx / cam.resx) / pm.tile) * pm.tilesX + (idx % cam.resx) / pm.tile) % pm.world != pm.rank) return;
     Ray ray = gbufPrimaryRay(cam, idx % cam.resx, idx / cam.resx);
-    if (makeRaySlab(ray).cls != 0) {
+    if (raySetAside(makeRaySlab(ray).cls)) {
         const int at = atomicAdd(&pc->deferCount, 1);
         if (at < kDeferCap) pc->deferred[at] = idx;
     }

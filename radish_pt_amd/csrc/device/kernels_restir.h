@@ -295,7 +295,7 @@ RD_DEV bool restirRayIsLiteral(v3 a, v3 b, bool any) {
     } else {
         ray = Ray{a, b};
     }
-    return makeRaySlab(ray).cls != 0;
+    return raySetAside(makeRaySlab(ray).cls);
 }
 constexpr int kRestirDeferCap = 256;  // == kWalkDeferCap (kernels_walk.h)
 

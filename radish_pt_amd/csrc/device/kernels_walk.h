@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
                         hitPrim = -1;
                         hitBary = mk2(0.f, 0.f);
                         found = false;
-                        if (!(DEFER && deferAll && rs.cls != 0 && end != 0)) {  // else: k_trace_wg_list has this ray
+                        if (!(DEFER && deferAll && raySetAside(rs.cls) && end != 0)) {  // else: k_trace_wg_list has this ray
                             nRays++;
                             state = W_TRACE;
                         }

@@ -53,6 +53,11 @@ RD_DEV RaySlab makeRaySlab(const Ray &r) {
     return s;
 }
 
+// Is a ray of this class worth setting aside for a workgroup-per-ray launch (k_trace_wg_list, k_gbuffer_literal)?  Classes 1-4
+// wander through the tree for thousands of box steps.  Class 5 does not: a non-finite ray — ReSTIR's zero-length shadow segment of
+// an empty reservoir gives a NaN direction, 5 % of a frame's segments — fails the root's box test at once and stays in the walker.
+RD_DEV bool raySetAside(int cls) { return cls >= 1 && cls <= 4; }
+
 RD_DEV bool between(float x, float mn, float mx) { return x >= mn && x <= mx; }  // mathUtil.h:34-36
 RD_DEV bool distMinMax(float a1, float a2, float b1, float b2, float &tMin) {     // bvh.h:72-78
     tMin = c_fminf(a1, a2);

@@ -1025,6 +1025,20 @@ int rdh_restir_read(rdh_ctx *c, int which, void *hostOut) {
     return RDH_OK;
 }
 
+long long rdh_restir_read_scratch(rdh_ctx *c, int which, void *hostOut, long long maxBytes) {
+    if (!c || which < 0 || which > 2) return RDH_ERR_ARGS;
+    if (!c->splitBuf) return fail(c, RDH_ERR_STATE, "rdh_restir_read_scratch: no split pass 1 has run");
+    const size_t slots = (size_t)c->splitSlots;
+    const char *base = static_cast<const char *>(c->splitBuf);
+    const char *src = which == 0 ? base + slots * (48 + 16) : (which == 1 ? base + slots * (48 + 16 + 24) : base + slots * 152);
+    const size_t bytes = which == 2 ? 16 + 2 * sizeof(int) * kRestirDeferCap : slots * 24;
+    if (!hostOut) return (long long)bytes;
+    if (maxBytes < (long long)bytes) return fail(c, RDH_ERR_ARGS, "rdh_restir_read_scratch: buffer too small");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(hostOut, src, bytes, hipMemcpyDeviceToHost));
+    return (long long)bytes;
+}
+
 // ---- collectives: RCCL over xGMI, called from C++ (no reference counterpart) -----------------------
 // One process per GPU: every rank creates its context, rank 0 makes a 128-byte id (rdh_comm_unique_id) and hands it to the
 // others by whatever channel the host has (the Python harness broadcasts it over torch.distributed's store, a C++ host can

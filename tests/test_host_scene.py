@@ -14,7 +14,7 @@ def test_hip_library_exports_every_declared_symbol():
     from radish_pt_amd import api
 
     header = open(os.path.join(ROOT, "include", "radish_hip.h")).read()
-    declared = sorted(set(re.findall(r"^(?:int|void|const char \*|int32_t)\s*(rdh_[a-z_]+)\s*\(", header, re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|long long|void|const char \*|int32_t)\s*(rdh_[a-z_]+)\s*\(", header, re.M)))
     assert declared == sorted(api.EXPORTS), "api.EXPORTS is out of sync with include/radish_hip.h"
     lib = ctypes.CDLL(api.HIP_LIB_PATH)
     for name in declared:
