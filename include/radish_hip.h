@@ -279,8 +279,9 @@ int rdh_profile_reset(rdh_ctx *ctx);
 int rdh_profile_read(rdh_ctx *ctx, double *totalMs, int64_t *launches);
 
 /* Diagnostic builds only (-DRD_PERSIST_STAMPS): wall-clock stamps (100 MHz ticks) of the last persistent launch —
- * [0][w] wave w started, [1][w] it found the pixel supply dry, [2][w] it ended.  RDH_ERR_UNSUPPORTED otherwise. */
-int rdh_debug_persist_stamps(rdh_ctx *ctx, uint64_t *out3x4096);
+ * [0][w] wave w started, [1][w] it found the pixel supply dry, [2][w] it ended, [3][w] ticks it spent tracing literal-class rays
+ * whole, [4][w] how many of those it had.  RDH_ERR_UNSUPPORTED otherwise. */
+int rdh_debug_persist_stamps(rdh_ctx *ctx, uint64_t *out5x4096);
 /* Diagnostic builds only (-DRD_PERSIST_PHASES): of the last persistent launch, summed over its waves — [0..5] s_memtime
  * ticks (100 MHz) spent in raygen / whole-wave rays / box loop / leaf tests / retire / shading, [6] total; [8] box
  * wave-steps, [9] box lane-steps, [10] leaf calls, [11] leaf lanes, [12] shade calls, [13] shade lanes, [14] raygen calls,

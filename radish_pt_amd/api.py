@@ -469,7 +469,7 @@ class Context:
         return ms.value, n.value
 
     def debug_persist_stamps(self):
-        out = np.zeros((3, 4096), dtype=np.uint64)
+        out = np.zeros((5, 4096), dtype=np.uint64)
         self.check(lib().rdh_debug_persist_stamps(self.h, out.ctypes.data))
         return out
 

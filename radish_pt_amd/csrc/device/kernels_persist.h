@@ -50,8 +50,9 @@ constexpr int kDeferCap = 256;  // rays k_gbuffer_literal takes: one per workgro
 struct PersistCounters {
     int blockHead;  // next 8x8 pixel block beyond the static first round (see k_pt_persistent)
     int deferCount;  // literal-class primary rays of the frame (k_gbuffer_find_literal); above kDeferCap none is set aside
-#ifdef RD_PERSIST_STAMPS  // diagnostic build only: when each wave started, ran out of pixels, and ended (wall clock)
-    unsigned long long stamp[3][4096];
+#ifdef RD_PERSIST_STAMPS  // diagnostic build only: when each wave started, ran out of pixels, and ended (wall clock);
+    // [3] wall-clock ticks it spent tracing literal-class rays whole, [4] how many such rays
+    unsigned long long stamp[5][4096];
 #endif
 #ifdef RD_PERSIST_PHASES  // diagnostic build only: where the waves' time goes (s_memtime ticks summed over waves) and how full
     // the wave is in each phase: [0..5] ticks in raygen / literal+coop / box loop / leaf / retire / shade, [6] total;
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
 #ifdef RD_PERSIST_STAMPS
     const int gw = int(blockIdx.x);
     bool stampedDry = false;
+    unsigned long long litTicks = 0, litRays = 0;
     if (lane == 0 && gw < 4096) pc->stamp[0][gw] = wall_clock64();
 #endif
 
@@ -372,6 +374,10 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         // ---------------- literal-class rays: traced whole by the whole wave (traverse.h, coopTraceWhole) ----------------
         {
             unsigned long long lit = __ballot(state == PS_TRACE && rayCls != 0 && node == 0 && pending < 0 && end != 0);
+#ifdef RD_PERSIST_STAMPS
+            const unsigned long long litT0 = wall_clock64();
+            litRays += (unsigned long long)__popcll(lit);
+#endif
             while (lit) {
                 const int L = __ffsll((long long)lit) - 1;
                 lit &= lit - 1ull;
@@ -392,6 +398,9 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                     }
                 }
             }
+#ifdef RD_PERSIST_STAMPS
+            litTicks += wall_clock64() - litT0;
+#endif
         }
         PH_MARK(1);
         // ---------------- box steps ----------------
@@ -593,7 +602,11 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         for (int i = 0; i < 16; i++) atomicAdd(&pc->phase[i], phT[i]);
 #endif
 #ifdef RD_PERSIST_STAMPS
-    if (lane == 0 && gw < 4096) pc->stamp[2][gw] = wall_clock64();
+    if (lane == 0 && gw < 4096) {
+        pc->stamp[2][gw] = wall_clock64();
+        pc->stamp[3][gw] = litTicks;
+        pc->stamp[4][gw] = litRays;
+    }
 #endif
     if (COUNT) flushCounters(s.counters, nClosest, nAny, nHits, ws);
 }

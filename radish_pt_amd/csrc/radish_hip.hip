@@ -1416,11 +1416,11 @@ int rdh_profile_read(rdh_ctx *c, double *totalMs, int64_t *launches) {
     return RDH_OK;
 }
 
-int rdh_debug_persist_stamps(rdh_ctx *c, uint64_t *out3x4096) {
-    if (!c || !out3x4096) return RDH_ERR_ARGS;
+int rdh_debug_persist_stamps(rdh_ctx *c, uint64_t *out5x4096) {
+    if (!c || !out5x4096) return RDH_ERR_ARGS;
 #ifdef RD_PERSIST_STAMPS
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out3x4096, c->dPersist->stamp, sizeof(unsigned long long) * 3 * 4096, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out5x4096, c->dPersist->stamp, sizeof(unsigned long long) * 5 * 4096, hipMemcpyDeviceToHost));
     return RDH_OK;
 #else
     return fail(c, RDH_ERR_UNSUPPORTED, "library built without RD_PERSIST_STAMPS");

@@ -23,3 +23,11 @@ print("mean wave lifetime / span = %.3f" % ((end - start).mean() / end.max()))
 for frac in (0.5, 0.25, 0.1, 0.02):
     # time at which only `frac` of the waves are still running
     print(f"  waves still running <= {frac:4.0%} after {np.percentile(end, 100 * (1 - frac)):.1f} us")
+lit_us, lit_n = st[3, :n] / 100.0, st[4, :n]
+print(f"literal-class rays traced whole: {int(lit_n.sum())} in {int((lit_n > 0).sum())} waves; per wave with one: median {np.median(lit_us[lit_n > 0]) if (lit_n > 0).any() else 0:.1f} us, max {lit_us.max():.1f} us")
+order = np.argsort(end)[::-1]
+for k in (16, 64, 256):
+    top = order[:k]
+    print(f"  the {k:3d} waves that end last: end >= {end[top].min():.1f} us; {int((lit_n[top] > 0).sum())} of them traced a literal-class ray (mean {lit_us[top].mean():.1f} us there); whole launch: {100 * (lit_n > 0).mean():.1f} % of waves")
+# what the launch would look like if those waves had ended `lit_us` earlier
+print(f"  span if literal traces were free: {np.max(end - lit_us):.1f} us (now {end.max():.1f})")
