@@ -309,6 +309,17 @@ def test_config4_restir_1080p_split_equals_fused(gpu_ctx, reuse):
             assert gpu_ctx.restir_read(1).tobytes() == other.restir_read(1).tobytes(), f"reservoirs, frame {f}"
             ca, cb = gpu_ctx.counters(), other.counters()
             assert ca == cb and ca["closestRays"] == n and ca["anyRays"] > 0.3 * n, (ca, cb)
+            # the rays set aside for the workgroup-per-ray launches are the few finite literal-class ones: the zero-length shadow
+            # segments of empty reservoirs (NaN direction, ~5 % of the frame) must not be listed, or the lists overflow their 256
+            # entries and every literal-class ray stays in the walker (rdh_restir_read_scratch)
+            lists = gpu_ctx.restir_read_scratch(2)
+            assert 0 < lists[0] <= 256 and 0 <= lists[1] <= 256, lists[:4]
+            segs = gpu_ctx.restir_read_scratch(1)
+            assert segs.shape == (n, 6)
+            degenerate = int((np.abs(segs[:, 0:3] - segs[:, 3:6]).max(axis=1) == 0).sum())
+            assert degenerate > 256, "this frame is expected to hold zero-length segments (the case the lists must skip)"
+            listed = lists[260:260 + int(lists[1])]
+            assert not (np.abs(segs[listed, 0:3] - segs[listed, 3:6]).max(axis=1) == 0).any()
             gb.update(cam)
         assert float(img_a.mean()) > 0.05
     finally:
