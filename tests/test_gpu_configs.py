@@ -315,8 +315,9 @@ def test_config4_restir_1080p_split_equals_fused(gpu_ctx, reuse):
             lists = gpu_ctx.restir_read_scratch(2)
             assert 0 < lists[0] <= 256 and 0 <= lists[1] <= 256, lists[:4]
             segs = gpu_ctx.restir_read_scratch(1)
-            assert segs.shape == (n, 6)
-            degenerate = int((np.abs(segs[:, 0:3] - segs[:, 3:6]).max(axis=1) == 0).sum())
+            assert segs.shape[0] >= n and segs.shape[1] == 6  # one slot per lane of every 8x8 block, NaN where there is no segment
+            with np.errstate(invalid="ignore"):
+                degenerate = int((np.abs(segs[:, 0:3] - segs[:, 3:6]).max(axis=1) == 0).sum())
             assert degenerate > 256, "this frame is expected to hold zero-length segments (the case the lists must skip)"
             listed = lists[260:260 + int(lists[1])]
             assert not (np.abs(segs[listed, 0:3] - segs[listed, 3:6]).max(axis=1) == 0).any()
