@@ -168,8 +168,13 @@ __global__ __launch_bounds__(kScheduleThreads) void k_persist_schedule(unsigned 
 #define RD_PERSIST_WAVES 1
 #endif
 #ifdef RD_PERSIST_PHASES
-#define PH_MARK(i) do { unsigned long long _n = __builtin_amdgcn_s_memtime(); phT[i] += _n - phLast; phLast = _n; } while (0)
-#define PH_COUNT(i, mask) do { phT[i] += 1ull; phT[(i) + 1] += (unsigned long long)__popcll(mask); } while (0)
+#ifdef RD_PERSIST_PHASES_DRAIN  // count only what happens after this wave has found the pixel supply dry
+#define PH_ON exhausted
+#else
+#define PH_ON true
+#endif
+#define PH_MARK(i) do { unsigned long long _n = __builtin_amdgcn_s_memtime(); if (PH_ON) phT[i] += _n - phLast; phLast = _n; } while (0)
+#define PH_COUNT(i, mask) do { if (PH_ON) { phT[i] += 1ull; phT[(i) + 1] += (unsigned long long)__popcll(mask); } } while (0)
 #else
 #define PH_MARK(i) do { } while (0)
 #define PH_COUNT(i, mask) do { } while (0)
@@ -597,7 +602,12 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         PH_MARK(5);
     }
 #ifdef RD_PERSIST_PHASES
+#ifdef RD_PERSIST_PHASES_DRAIN
+    phT[6] = phT[0] + phT[1] + phT[2] + phT[3] + phT[4] + phT[5];
+    (void)phStart;
+#else
     phT[6] = __builtin_amdgcn_s_memtime() - phStart;
+#endif
     if (lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(&pc->phase[i], phT[i]);
 #endif
