@@ -16,9 +16,13 @@ N > 1:  one rank per GPU over RCCL.  `python bench.py --gpus N` with no WORLD_SI
 
 Frames in flight: `value` and `ms_per_step` are ALWAYS measured with ONE frame in flight (F = 1: frame s+1 is issued when frame
 s has been enqueued on the same stream; ms_per_step is then a frame latency as well as a rate), at every N, so the scaling
-curve compares like with like.  A second, labelled figure `pipelined` re-times the same K frames with F = max(2, N) frames in
-flight (each on its own stream and buffers, persistent grids divided by F so the slots together fill the GPU once): that one is
-throughput only.  `--frames-in-flight F` overrides the headline's F (then `config.frames_in_flight` says so).
+curve compares like with like.  A second, labelled figure `pipelined` re-times the same K frames with F = max(3, N) frames in
+flight (each on its own stream and buffers, persistent grids divided by F so the slots together fill the GPU once; on one GPU
+F = 3 measured best: 2.66 ms against 2.80 at F = 2 and 3.04 at F = 4): that one is throughput only.
+`--frames-in-flight F` overrides the headline's F (then `config.frames_in_flight` says so).
+Frames in flight need HARDWARE queues of their own: ROCm gives a process 4 by default and deals further streams onto them round
+robin, so two contexts (three streams each) can land on one queue and run one after the other (measured: F = 2 at 4.71 ms per
+frame instead of 2.80).  bench.py therefore sets GPU_MAX_HW_QUEUES=32 before the HIP runtime starts, unless the caller has set it.
 
 value = (closest-hit + any-hit rays actually traced in the K timed frames, all ranks) / (max-over-ranks wall time).
 Ray counts are exact device counters taken in an untimed pass over the same Sobol rows (the counters cost atomics,
@@ -100,6 +104,7 @@ def self_launch(args):
 
 def main():
     args = parse_args()
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")  # before the HIP runtime starts (children of self_launch inherit it)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
 
@@ -246,7 +251,7 @@ def main():
     m = measure(F)
     pipelined = None
     if not args.no_pipelined and F == 1:
-        Fp = min(8, max(2, world))
+        Fp = min(8, max(3, world))
         mp_ = measure(Fp)
         pipelined = {"frames_in_flight": Fp, "value": round(mp_["rays_total"] / mp_["elapsed"] / 1e6, 3), "unit": "Mrays/s",
                      "ms_per_step": round(mp_["elapsed"] / K * 1e3, 4),
