@@ -22,7 +22,7 @@ F = 3 measured best: 2.66 ms against 2.80 at F = 2 and 3.04 at F = 4): that one 
 `--frames-in-flight F` overrides the headline's F (then `config.frames_in_flight` says so).
 Frames in flight need HARDWARE queues of their own: ROCm gives a process 4 by default and deals further streams onto them round
 robin, so two contexts (three streams each) can land on one queue and run one after the other (measured: F = 2 at 4.71 ms per
-frame instead of 2.80).  bench.py therefore sets GPU_MAX_HW_QUEUES=32 before the HIP runtime starts, unless the caller has set it.
+frame instead of 2.80).  bench.py therefore sets GPU_MAX_HW_QUEUES=16 before the HIP runtime starts, unless the caller has set it.
 
 value = (closest-hit + any-hit rays actually traced in the K timed frames, all ranks) / (max-over-ranks wall time).
 Ray counts are exact device counters taken in an untimed pass over the same Sobol rows (the counters cost atomics,
@@ -104,7 +104,7 @@ def self_launch(args):
 
 def main():
     args = parse_args()
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")  # before the HIP runtime starts (children of self_launch inherit it)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime starts (children of self_launch inherit it)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
 
@@ -421,7 +421,36 @@ def main():
                       f"{ref_d[p] if p >= 0 else None} {ref_i[p] if p >= 0 else None}; all-cores oracle equal to one thread: {all_equal}",
                       file=sys.stderr, flush=True)
                 rc = 3
-        elif world > 1 or args.no_cpu_baseline:
+        elif world > 1:
+            out["cpu_baseline"] = None
+            # Parity of the PARTITIONED frame (no oracle at N > 1: it needs minutes per frame): rank 0 renders the last timed frame
+            # once more alone — one rank, whole frame, same Sobol row, same kernel structure — and compares it bit for bit with what
+            # the all-gathers and rdh_untile left on this rank.  (The one-rank frame itself is checked against the oracle at N = 1.)
+            s_last = Wm + K - 1
+            last = slots[s_last % F]
+            torch.cuda.synchronize()
+            with torch.cuda.stream(last.stream):
+                solo = api.Context(dev.index)
+                solo.upload_scene(sd)
+                solo.set_camera(cam)
+                solo.set_partition(0, 1, args.tile)
+                solo_d = torch.zeros(W * H, 3, device=dev)
+                solo_i = torch.zeros(W * H, 3, device=dev)
+                solo.path_trace(solo_d, solo_i, 0, s_last % api.SOBOL_SAMPLE_NUM, depth, flags)
+                solo.synchronize()
+            diff = (solo_d.view(torch.int32) != last.frame_d.view(torch.int32)) | (solo_i.view(torch.int32) != last.frame_i.view(torch.int32))
+            n_bad = int(diff.sum())
+            out["parity_check"] = {"pixels": int(W * H), "bit_exact": n_bad == 0,
+                                   "against": "the same frame rendered by rank 0 alone (one rank, whole frame); that frame is checked "
+                                              "against the CPU oracle by the N = 1 run"}
+            solo.close()
+            if n_bad:
+                p = int(torch.nonzero(diff.any(dim=1))[0])
+                print(f"bench.py: PARITY FAILURE at {world} ranks — {n_bad} floats of the gathered frame differ from the one-rank frame; "
+                      f"first at pixel {p} (x={p % W}, y={p // W}, tile {(p // W) // args.tile * ((W + args.tile - 1) // args.tile) + (p % W) // args.tile})",
+                      file=sys.stderr, flush=True)
+                rc = 3
+        elif args.no_cpu_baseline:
             out["cpu_baseline"] = None
         if rc == 0:
             print(json.dumps(out), flush=True)
