@@ -75,7 +75,7 @@ def parse_args():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "persistent"),
                     choices=["mega", "wavefront", "wavefront_sort", "wavefront2", "wavefront_sort2", "persistent"],
-                    help="wavefront2 / wavefront_sort2: the wavefront pipeline as two sub-frames on two streams (RDH_PT_WF_SUBFRAMES)")
+                    help="wavefront2 / wavefront_sort2: the wavefront pipeline as three sub-frames on three streams (RDH_PT_WF_SUBFRAMES)")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_small", "teapots", "teapots_lights", "teasets_1m"])
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")

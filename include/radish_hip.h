@@ -102,8 +102,8 @@ typedef struct rdh_counters {
                                   instead of setting them aside for the workgroup-per-ray launch (k_gbuffer_literal)   */
 #define RDH_PT_PARTITION_GBUFFER 512u /* rdh_gbuffer_render on a tile partition: render the records of THIS rank's tiles only
                                   (complete the planes with rdh_gbuffer_exchange*); default: every rank renders the whole frame */
-#define RDH_PT_WF_SUBFRAMES 2048u /* wavefront only: two sub-frames (interleaved 8x8 blocks) as two pipelines on two streams, so that
-                                  one pipeline's stage tails overlap the other's stage bodies (frames of >= 2 048 blocks) */
+#define RDH_PT_WF_SUBFRAMES 2048u /* wavefront only: three sub-frames (8x8 blocks dealt round robin) as three pipelines on three streams, so
+                                  that one pipeline's stage tails overlap the others' stage bodies (frames of >= 2 048 blocks) */
 #define RDH_PT_RESTIR_FUSED 1024u /* rdh_restir_direct: round 1's pass 1, one lane per pixel with both walks inside the kernel
                                   (k_restir_pass1), instead of raygen / walk / RIS / walk / resolve (default; same results) */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */

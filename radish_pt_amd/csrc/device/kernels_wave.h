@@ -9,7 +9,7 @@
 //   * all arithmetic is the same device functions the megakernel calls.
 //
 // Launch structure per frame (maxDepth = D):  memset(counters) · raygen · for k = 0..D { trace(k) · shade(k) } · finish
-// (optionally as two sub-frames on two streams, see k_wf_raygen; the material sort happens inside shade, see k_wf_shade)
+// (optionally as three sub-frames on three streams, see k_wf_raygen; the material sort happens inside shade, see k_wf_shade)
 //   trace(k)  = any-hit for the shadow rays emitted by shade(k-1)  +  closest-hit for the rays of bounce k
 //   shade(k)  = surface fetch for hit k, emitter/miss termination, then bounce body k+1 (NEE sample → shadow
 //               queue, BSDF sample → next ray queue) with wave64 ballot compaction

@@ -26,6 +26,8 @@
 
 using namespace rd;
 
+constexpr int kWfParts = 3;  // sub-frame pipelines of the wavefront path (RDH_PT_WF_SUBFRAMES)
+
 struct rdh_ctx {
     int device = 0;
     hipStream_t ownStream = nullptr;
@@ -91,7 +93,9 @@ struct rdh_ctx {
     size_t commSendFloats[2] = {0, 0}, commRecvFloats = 0;
 
     // wavefront workspace
-    WaveWorkspace wf[2] = {};  // one per sub-frame (RDH_PT_WF_SUBFRAMES: two pipelines on two streams)
+    WaveWorkspace wf[kWfParts] = {};  // one per sub-frame (RDH_PT_WF_SUBFRAMES: three pipelines on three streams)
+    hipStream_t wfStream = nullptr;    // the third pipeline's stream (the first two use stream and sideStream)
+    hipEvent_t evWfJoin3 = nullptr;
     long long wfCapacity = 0;   // path slots each workspace holds
     std::vector<void *> wfAllocs;
     hipEvent_t evWfFork = nullptr, evWfJoin = nullptr;
@@ -228,13 +232,13 @@ int wfAlloc(rdh_ctx *c, T **out, size_t count) {
 
 // Workspace for the wavefront pipeline: 152 B of path state + 3 queue slots per path slot, per sub-frame.
 int wavefrontEnsure(rdh_ctx *c, const PixelMap &pm) {
-    long long slots = (long long)pm.numBlocks * 64;  // a sub-frame of two holds at most half (+ one block)
+    long long slots = (long long)pm.numBlocks * 64;  // a sub-frame of three holds a third (+ one block); sized for half
     if (c->wfCapacity >= slots) return RDH_OK;
     for (void *p : c->wfAllocs) hipFree(p);
     c->wfAllocs.clear();
     c->wfCapacity = 0;
     const size_t n0 = (size_t)slots, n1 = (size_t)((pm.numBlocks + 1) / 2) * 64;
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < kWfParts; h++) {
         WaveWorkspace &w = c->wf[h];
         const size_t n = h == 0 ? n0 : n1;  // workspace 0 also serves the one-pipeline mode (whole frame)
         int rc;
@@ -248,6 +252,8 @@ int wavefrontEnsure(rdh_ctx *c, const PixelMap &pm) {
     if (!c->evWfFork) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->evWfFork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->evWfJoin, hipEventDisableTiming));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->wfStream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->evWfJoin3, hipEventDisableTiming));
     }
     c->wfCapacity = slots;
     return RDH_OK;
@@ -270,16 +276,18 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
             c->wfGrid[q] = g < kPersistentGrid ? g : kPersistentGrid;
         }
     }
-    // Two sub-frames (interleaved 8x8 blocks) as two pipelines on two streams: every stage of one pipeline ends on its longest
-    // ray while the other pipeline's stage fills the chip.  Each pipeline launches half-size grids so that the two together are
-    // resident.  Small frames stay one pipeline.
-    const int parts = ((flags & RDH_PT_WF_SUBFRAMES) && pm.numBlocks >= 2048) ? 2 : 1;
-    if (parts == 2) {
+    // Three sub-frames (8x8 blocks dealt round robin) as three pipelines on three streams: every stage of one pipeline ends on its
+    // longest ray while the stages of the others fill the chip.  Each pipeline launches a third of the resident grid.  Measured on
+    // the teapots / Cornell frame: one pipeline 12.3 / 5.14 ms, two 10.5 / 4.70, three 10.2 / 4.58, four 10.4 / 5.0.  Small frames
+    // stay one pipeline.
+    const int parts = ((flags & RDH_PT_WF_SUBFRAMES) && pm.numBlocks >= 2048) ? kWfParts : 1;
+    hipStream_t sts[kWfParts] = {c->stream, c->sideStream, c->wfStream};
+    if (parts >= 2) {
         HIP_TRY(c, hipEventRecord(c->evWfFork, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evWfFork, 0));
+        for (int h = 1; h < parts; h++) HIP_TRY(c, hipStreamWaitEvent(sts[h], c->evWfFork, 0));
     }
     for (int h = 0; h < parts; h++) {
-        hipStream_t st = h == 0 ? c->stream : c->sideStream;
+        hipStream_t st = sts[h];
         WaveWorkspace &w = c->wf[h];
         const unsigned nLocal = (unsigned)(pm.numBlocks - h + parts - 1) / (unsigned)parts;
         const unsigned gridBlk = (((nLocal + 3u) / 4u + 7u) / 8u) * 8u;
@@ -288,7 +296,7 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     }
     for (int k = 0; k <= maxDepth; k++) {
         for (int h = 0; h < parts; h++) {  // interleaved issue: stage k of both pipelines before stage k + 1 of either
-            hipStream_t st = h == 0 ? c->stream : c->sideStream;
+            hipStream_t st = sts[h];
             WaveWorkspace &w = c->wf[h];
             long pe = (h == 0 && parts == 1) ? profBegin(c, flags) : -1;
             if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(c->wfGrid[1] / parts), dim3(256), 0, st, c->ds, w, k);
@@ -298,14 +306,16 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
         }
     }
     for (int h = 0; h < parts; h++) {
-        hipStream_t st = h == 0 ? c->stream : c->sideStream;
+        hipStream_t st = sts[h];
         const unsigned nLocal = (unsigned)(pm.numBlocks - h + parts - 1) / (unsigned)parts;
         const unsigned gridBlk = (((nLocal + 3u) / 4u + 7u) / 8u) * 8u;
         hipLaunchKernelGGL(k_wf_finish, dim3(gridBlk), dim3(256), 0, st, pm, c->wf[h], iter, d_direct, d_indirect, h, parts);
     }
-    if (parts == 2) {
+    if (parts >= 2) {
         HIP_TRY(c, hipEventRecord(c->evWfJoin, c->sideStream));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evWfJoin, 0));
+        HIP_TRY(c, hipEventRecord(c->evWfJoin3, c->wfStream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evWfJoin3, 0));
     }
     return RDH_OK;
 }
@@ -436,6 +446,11 @@ void rdh_destroy(rdh_ctx *c) {
     }
     if (c->blockEma) hipFree(c->blockEma);
     if (c->evFrame) hipEventDestroy(c->evFrame);
+    if (c->wfStream) {
+        hipStreamSynchronize(c->wfStream);
+        hipStreamDestroy(c->wfStream);
+    }
+    if (c->evWfJoin3) hipEventDestroy(c->evWfJoin3);
     if (c->evWfFork) hipEventDestroy(c->evWfFork);
     if (c->evWfJoin) hipEventDestroy(c->evWfJoin);
     if (c->evStart) hipEventDestroy(c->evStart);
@@ -459,6 +474,7 @@ int rdh_set_stream(rdh_ctx *c, void *s) {
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->sideStream) HIP_TRY(c, hipStreamSynchronize(c->sideStream));
+        if (c->wfStream) HIP_TRY(c, hipStreamSynchronize(c->wfStream));
         c->orderValid = false;
         c->stream = ns;
     }

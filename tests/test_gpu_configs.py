@@ -49,7 +49,7 @@ def test_config1_cornell_400x400_depth4_16spp(gpu_ctx, cornell_full):
     gpu_ctx.set_camera(cam)
     for name, flags in (("persistent", api.RDH_PT_PERSISTENT), ("megakernel", api.RDH_PT_MEGAKERNEL),
                         ("wavefront+sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL),
-                        ("wavefront+sort, two sub-frames", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES)):
+                        ("wavefront+sort, sub-frames", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES)):
         d = torch.zeros(W * H, 3, device="cuda")
         i = torch.zeros(W * H, 3, device="cuda")
         gpu_ctx.counters_reset()
