@@ -20,6 +20,8 @@
 
 namespace rd {
 
+constexpr int kWfLitCap = 8192;   // per stage; rays beyond it stay in the ordinary queues
+constexpr int kWfLitShadow = 0x40000000;
 constexpr int kMaxWaveDepth = 32;  // 4 + 7*depth Sobol dimensions <= 200 → depth <= 28
 
 // Every counter sits on its own 128-byte line: same-address returning atomics serialise at ~12 ns each, and counters that share
@@ -32,6 +34,7 @@ struct alignas(128) WaveCounter {
 struct WaveCounters {
     WaveCounter rayCount[kMaxWaveDepth + 2];     // rays of bounce k (written by raygen / shade(k-1))
     WaveCounter shadowCount[kMaxWaveDepth + 2];  // shadow rays emitted by shade(k)
+    WaveCounter litCount[kMaxWaveDepth + 2];     // literal-class rays (both kinds) that shade(k-1) set aside for trace(k)
     WaveCounter traceHead[kMaxWaveDepth + 2];
     WaveCounter shadeHead[kMaxWaveDepth + 2][4];
 };
@@ -49,6 +52,8 @@ struct WaveWorkspace {
     int4 *hit;        // {primId, bary.x, bary.y, shading class of the hit's material}
     int *rayq[2];
     int *shadowq;
+    int *litq[2];     // path slots of rays that look literal-class (bit 30: a shadow ray); trace(k) starts them first, one per wave
+    int litCap;       // entries a stage may hold: min(kWfLitCap, 64 * waves of the trace grid)
     WaveCounters *ctr;
 };
 
@@ -169,9 +174,25 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
     v2 hitBary = mk2(0.f, 0.f);
     bool occluded = false;
 
+    // Rays that shade(k-1) found to look literal-class (they wander through the tree for thousands of box steps and are traced by
+    // the whole wave, 90 us median on the teapots scene) start FIRST, one per wave, lane by lane: picked up with a late packet one
+    // of them is what the stage ends on (measured ceiling: 0.5-0.95 ms of the teapots frame).
+    bool firstRound = true;
     for (;;) {
         // ---- hand new items to idle lanes ----
-        unsigned long long idle = __ballot(!alive);
+        bool doStart = false;  // this lane takes an item in this round: kind and path slot go straight into isShadow / p
+        if (firstRound) {
+            firstRound = false;
+            const int nLit = c->litCount[k].v < w.litCap ? c->litCount[k].v : w.litCap;
+            const int it = globalWave() + int(threadIdx.x & 63u) * gridWaves();
+            if (it < nLit) {
+                const int e = w.litq[k & 1][it];
+                doStart = true;
+                isShadow = (e & kWfLitShadow) != 0;
+                p = e & (kWfLitShadow - 1);
+            }
+        }
+        unsigned long long idle = __ballot(!alive && !doStart);
         int nIdle = __popcll(idle);
         if (!exhausted && nIdle >= RD_REFILL_MIN) {
             int myRank = __popcll(idle & laneMaskLt());
@@ -188,43 +209,43 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
                 }
                 int avail = resEnd - resNext;
                 int give = (nIdle - taken) < avail ? (nIdle - taken) : avail;
-                if (!alive && myRank >= taken && myRank < taken + give) {
-                    int item = resNext + (myRank - taken);
+                if (!alive && !doStart && myRank >= taken && myRank < taken + give) {
+                    const int item = resNext + (myRank - taken);
+                    doStart = true;
                     isShadow = item < nShadow;
-                    Ray ray;
-                    if (isShadow) {
-                        p = w.shadowq[item];
-                        float4 x4 = w.prevPos[p], y4 = w.sht[p];
-                        v3 x = mk3(x4.x, x4.y, x4.z), y = mk3(y4.x, y4.y, y4.z);
-                        v3 dir = y - x;  // DevScene::testOcclusion's ray set-up (scene.h:304-311)
-                        float dist = length(dir);
-                        dir = dir / dist;
-                        tmax = dist - 1e-4f;
-                        ray = makeOffsetedRay(x, dir);
-                        nAny++;
-                    } else {
-                        p = rayq[item - nShadow];
-                        if (p >= 0) {
-                            float4 o = w.ro[p], d = w.rd[p];
-                            ray = Ray{mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z)};
-                            tmax = 3.402823466e+38f;
-                            nClosest++;
-                        } else {
-                            ray = Ray{mk3(0.f), mk3(0.f, 0.f, 1.f)};  // off-frame slot of bounce 0: nothing to trace
-                        }
-                    }
-                    if (p >= 0) {
-                        rs = makeRaySlab(ray);
-                        nodes = s.nodes[getMTBVHId(-ray.d)];
-                        node = 0;
-                        pending = -1;
-                        hitPrim = -1;
-                        occluded = false;
-                        alive = node != end;
-                    }
+                    p = isShadow ? w.shadowq[item] : rayq[item - nShadow];
                 }
                 resNext += give;
                 taken += give;
+            }
+        }
+        if (doStart) {
+            Ray ray;
+            if (isShadow) {
+                float4 x4 = w.prevPos[p], y4 = w.sht[p];
+                v3 x = mk3(x4.x, x4.y, x4.z), y = mk3(y4.x, y4.y, y4.z);
+                v3 dir = y - x;  // DevScene::testOcclusion's ray set-up (scene.h:304-311)
+                float dist = length(dir);
+                dir = dir / dist;
+                tmax = dist - 1e-4f;
+                ray = makeOffsetedRay(x, dir);
+                nAny++;
+            } else if (p >= 0) {
+                float4 o = w.ro[p], d = w.rd[p];
+                ray = Ray{mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z)};
+                tmax = 3.402823466e+38f;
+                nClosest++;
+            } else {
+                ray = Ray{mk3(0.f), mk3(0.f, 0.f, 1.f)};  // off-frame slot of bounce 0: nothing to trace
+            }
+            if (p >= 0) {
+                rs = makeRaySlab(ray);
+                nodes = s.nodes[getMTBVHId(-ray.d)];
+                node = 0;
+                pending = -1;
+                hitPrim = -1;
+                occluded = false;
+                alive = node != end;
             }
         }
         unsigned long long am = __ballot(alive);
@@ -349,11 +370,11 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
         const int n = c->rayCount[k].v;
         const int *hitq = w.rayq[k & 1];
         // queue entries of the packet's chunks, held until its last chunk has been shaded, then appended together
-        int pendP[kShadeChunks];
+        int pendP[kShadeChunks], pendQ[kShadeChunks];  // path slot; its ray-queue entry (-2 - slot: trace(k+1) has it on its first list)
         bool pendShadow[kShadeChunks], pendRay[kShadeChunks];
 #pragma unroll
         for (int j = 0; j < kShadeChunks; j++) {
-            pendP[j] = -1;
+            pendP[j] = pendQ[j] = -1;
             pendShadow[j] = pendRay[j] = false;
         }
         // unsorted: packets of kShadePacket = 256 records.  sorted: 256 .. kSortPacket = 1 024 records (multiples of 256), as large
@@ -381,6 +402,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                 for (int j = 0; j < kSortChunks; j++) {
                     const int i = base + j * 64 + lane;
                     pp[j] = (j * 64 + lane < packetEnd) ? hitq[i] : -1;
+                    if (pp[j] <= -2) pp[j] = -2 - pp[j];  // a ray trace(k) started first (literal-class list): same path slot
                 }
 #pragma unroll
                 for (int j = 0; j < kSortChunks; j++) {
@@ -405,10 +427,11 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
             const int subNow = sub;
             sub += 64;
             bool active = sorted ? (subNow + lane < packetEnd) : (item < n);
-            bool emitShadow = false, emitRay = false;
+            bool emitShadow = false, emitRay = false, litShadow = false, litRay = false, rayFirst = false;
             int p = -1;
             if (active) {
                 p = sorted ? mySorted[subNow + lane] : hitq[item];
+                if (p <= -2) p = -2 - p;  // (see the binning above)
                 active = p >= 0;
             }
             if (active) {
@@ -483,6 +506,11 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                             w.sht[p] = make_float4(lp.sampled.x, lp.sampled.y, lp.sampled.z, 0.f);
                             emitShadow = true;  // traced even when nothing can be added: sampleDirectLight tests
                                                 // occlusion before the single-sided rejection
+                            {  // a hint only (trace classifies the ray it builds): some component below 1.1e-6 of the length
+                                const v3 dl = lp.sampled - isec.pos;
+                                const float l2 = dot(dl, dl) * 1.21e-12f;
+                                litShadow = dl.x * dl.x < l2 || dl.y * dl.y < l2 || dl.z * dl.z < l2;
+                            }
                         }
                     }
                     w.prevPos[p] = make_float4(isec.pos.x, isec.pos.y, isec.pos.z, 0.f);
@@ -499,7 +527,25 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                     w.thr[p] = make_float4(throughput.x, throughput.y, throughput.z, 0.f);
                     w.rng[p] = make_uint2(rng.scramble, (unsigned)rng.ptr);
                     emitRay = true;
+                    litRay = fabs_(ray.d.x) < 1.1e-6f || fabs_(ray.d.y) < 1.1e-6f || fabs_(ray.d.z) < 1.1e-6f;
                 } while (false);
+            }
+            if (__ballot(litShadow || litRay) != 0ull) {  // rare: a few hundred rays per stage
+                int *lq = w.litq[(k + 1) & 1];
+                int *lc = &c->litCount[k + 1].v;
+                for (int kind = 0; kind < 2; kind++) {
+                    const bool pred = kind == 0 ? litShadow : litRay;
+                    const unsigned long long m = __ballot(pred);
+                    if (m == 0ull) continue;
+                    int at = 0;
+                    if (lane == 0) at = atomicAdd(lc, __popcll(m));
+                    at = __shfl(at, 0, 64) + __popcll(m & laneMaskLt());
+                    if (pred && at < w.litCap) {  // beyond the list's capacity the ray stays in its ordinary queue
+                        lq[at] = kind == 0 ? (p | kWfLitShadow) : p;
+                        if (kind == 0) emitShadow = false;  // nobody else reads the shadow queue
+                        else rayFirst = true;  // the ray queue is also shade(k+1)'s list of hits: the entry stays, marked as traced
+                    }
+                }
             }
             {
                 const int j = ((sub >> 6) - 1) & (kShadeChunks - 1);  // chunk just shaded, within its group of four (wave-uniform)
@@ -507,6 +553,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
                 for (int jj = 0; jj < kShadeChunks; jj++)
                     if (jj == j) {
                         pendP[jj] = p;
+                        pendQ[jj] = rayFirst ? -2 - p : p;
                         pendShadow[jj] = emitShadow;
                         pendRay[jj] = emitRay;
                     }
@@ -514,7 +561,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int
             // every fourth chunk, and at the last chunk of the queue (the loop then leaves or pulls the next packet): append
             if ((sub & (kShadePacket - 1)) == 0 || base + sub >= n) {
                 waveAppendN(pendShadow, pendP, w.shadowq, &c->shadowCount[k].v);
-                waveAppendN(pendRay, pendP, w.rayq[(k + 1) & 1], &c->rayCount[k + 1].v);
+                waveAppendN(pendRay, pendQ, w.rayq[(k + 1) & 1], &c->rayCount[k + 1].v);
 #pragma unroll
                 for (int jj = 0; jj < kShadeChunks; jj++) pendShadow[jj] = pendRay[jj] = false;
             }

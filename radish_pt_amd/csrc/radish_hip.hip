@@ -246,8 +246,10 @@ int wavefrontEnsure(rdh_ctx *c, const PixelMap &pm) {
             (rc = wfAlloc(c, &w.prevPos, n)) || (rc = wfAlloc(c, &w.accD, n)) || (rc = wfAlloc(c, &w.accI, n)) ||
             (rc = wfAlloc(c, &w.nee, n)) || (rc = wfAlloc(c, &w.sht, n)) || (rc = wfAlloc(c, &w.rng, n)) ||
             (rc = wfAlloc(c, &w.hit, n)) || (rc = wfAlloc(c, &w.rayq[0], n)) || (rc = wfAlloc(c, &w.rayq[1], n)) ||
-            (rc = wfAlloc(c, &w.shadowq, n)) || (rc = wfAlloc(c, &w.ctr, 1)))
+            (rc = wfAlloc(c, &w.shadowq, n)) || (rc = wfAlloc(c, &w.ctr, 1)) || (rc = wfAlloc(c, &w.litq[0], (size_t)kWfLitCap)) ||
+            (rc = wfAlloc(c, &w.litq[1], (size_t)kWfLitCap)))
             return rc;
+        w.litCap = 0;
     }
     if (!c->evWfFork) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->evWfFork, hipEventDisableTiming));
@@ -293,6 +295,10 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
         const unsigned gridBlk = (((nLocal + 3u) / 4u + 7u) / 8u) * 8u;
         HIP_TRY(c, hipMemsetAsync(w.ctr, 0, sizeof(WaveCounters), st));
         hipLaunchKernelGGL(k_wf_raygen, dim3(gridBlk), dim3(256), 0, st, c->ds, c->cam, pm, w, looper, h, parts);
+    }
+    for (int h = 0; h < parts; h++) {  // what a stage's literal-class list may hold: one entry per lane of the trace grid
+        const unsigned waves = (c->wfGrid[count ? 1 : 0] / (unsigned)parts) * 4u;
+        c->wf[h].litCap = (int)(waves * 64u < (unsigned)kWfLitCap ? waves * 64u : (unsigned)kWfLitCap);
     }
     for (int k = 0; k <= maxDepth; k++) {
         for (int h = 0; h < parts; h++) {  // interleaved issue: stage k of both pipelines before stage k + 1 of either
