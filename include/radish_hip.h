@@ -106,6 +106,8 @@ typedef struct rdh_counters {
                                   that one pipeline's stage tails overlap the others' stage bodies (frames of >= 2 048 blocks) */
 #define RDH_PT_RESTIR_FUSED 1024u /* rdh_restir_direct: round 1's pass 1, one lane per pixel with both walks inside the kernel
                                   (k_restir_pass1), instead of raygen / walk / RIS / walk / resolve (default; same results) */
+#define RDH_PT_WF_SMALL_LISTS 4096u /* wavefront only, for tests: the per-stage lists of literal-class rays hold 4 entries, so that the
+                                  overflow path (such rays stay in the ordinary queues) runs */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read            */

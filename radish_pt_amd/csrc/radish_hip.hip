@@ -299,6 +299,7 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     for (int h = 0; h < parts; h++) {  // what a stage's literal-class list may hold: one entry per lane of the trace grid
         const unsigned waves = (c->wfGrid[count ? 1 : 0] / (unsigned)parts) * 4u;
         c->wf[h].litCap = (int)(waves * 64u < (unsigned)kWfLitCap ? waves * 64u : (unsigned)kWfLitCap);
+        if (flags & RDH_PT_WF_SMALL_LISTS) c->wf[h].litCap = 4;  // tests: what does not fit stays in the ordinary queues
     }
     for (int k = 0; k <= maxDepth; k++) {
         for (int h = 0; h < parts; h++) {  // interleaved issue: stage k of both pipelines before stage k + 1 of either

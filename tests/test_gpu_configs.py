@@ -49,7 +49,10 @@ def test_config1_cornell_400x400_depth4_16spp(gpu_ctx, cornell_full):
     gpu_ctx.set_camera(cam)
     for name, flags in (("persistent", api.RDH_PT_PERSISTENT), ("megakernel", api.RDH_PT_MEGAKERNEL),
                         ("wavefront+sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL),
-                        ("wavefront+sort, sub-frames", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES)):
+                        ("wavefront+sort, sub-frames", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES),
+                        # the per-stage lists of literal-class rays cut to 4 entries: what does not fit stays in the ordinary queues
+                        ("wavefront, 4-entry first lists", api.RDH_PT_WAVEFRONT | api.RDH_PT_WF_SMALL_LISTS),
+                        ("wavefront+sort, 4-entry first lists", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SMALL_LISTS)):
         d = torch.zeros(W * H, 3, device="cuda")
         i = torch.zeros(W * H, 3, device="cuda")
         gpu_ctx.counters_reset()
