@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelM
 #ifndef RD_REFILL_MIN
 #define RD_REFILL_MIN 16  // refill once at least this many lanes are idle
 #endif
+#ifndef RD_WF_COOP_LONE  // a lone walking lane is walked by the whole wave (coopWalk): 0.5-1 % on either scene
+#define RD_WF_COOP_LONE 1
+#endif
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int k) {
@@ -253,7 +256,6 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
             if (exhausted) break;
             continue;
         }
-        const int minAlive = exhausted ? 1 : (64 - RD_REFILL_MIN + 1);
 
         // ---- literal-class rays: traced whole by the whole wave (traverse.h, coopTraceWhole) ----
         {
@@ -280,28 +282,44 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
                 }
             }
         }
-        // ---- box steps until enough lanes are parked on a leaf or enough lanes have finished ----
-        for (;;) {
+        // ---- box steps until a quarter of the lanes that entered the loop have stopped walking (parked on a leaf or finished):
+        // one ballot + popcount per step, as in k_walk_persistent; every walker here is of class 0 (the others were traced whole).
+        // (Until the end of round 2 this loop took two ballots per step, tested "enough lanes alive" as well and went through the
+        // class dispatch of boxTest: the teapots frame 10.0 -> 9.3 ms, the Cornell frame 4.6 -> 4.0 ms with three sub-frames.) ----
+        {
             bool walking = alive && pending < 0;
-            unsigned long long wm = __ballot(walking);
-            if (wm == 0ull) break;
-            unsigned long long pm = __ballot(alive && pending >= 0);
-            int nPark = __popcll(pm), nWalk = __popcll(wm);
-            if (pm != 0ull && nPark * RD_LEAF_DEN >= (nWalk + nPark) * RD_LEAF_NUM) break;
-            if (nWalk + nPark < minAlive) break;
-            if (walking) {
-                float4 lo = nodes[node].lo_prim;
-                float4 hi = nodes[node].hi_next;
-                float boundDist;
-                if (COUNT) ws.nodes++;
-                bool boundHit = boxTest(lo, hi, rs, boundDist);
-                if (boundHit && boundDist < tmax) {
-                    pending = __float_as_int(lo.w);
-                    node++;
-                } else {
-                    node = __float_as_int(hi.w);
+            const int nStart = __popcll(__ballot(walking));
+#if RD_WF_COOP_LONE
+            if (nStart == 1) {  // a lone walker (the end of a stage): the whole wave tests 64 boxes ahead for it
+                const int L = __ffsll((long long)__ballot(walking)) - 1;
+                CoopResult cr = coopWalk(readlanePtr(nodes, L), readlaneI(node, L), end, readlaneRay(rs, L), readlaneF(tmax, L), RD_COOP_WINDOWS);
+                if (int(threadIdx.x & 63u) == L) {
+                    node = cr.node;
+                    pending = cr.pending;
+                    if (COUNT) ws.nodes += cr.visited;
+                    alive = (node != end) || pending >= 0;
                 }
-                alive = (node != end) || pending >= 0;
+            } else
+#endif
+            if (nStart > 0) {
+                const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
+                do {
+                    if (walking) {
+                        float4 lo = nodes[node].lo_prim;
+                        float4 hi = nodes[node].hi_next;
+                        float boundDist;
+                        if (COUNT) ws.nodes++;
+                        bool boundHit = aabbFast(lo, hi, rs, boundDist);
+                        if (boundHit && boundDist < tmax) {
+                            pending = __float_as_int(lo.w);
+                            node++;
+                        } else {
+                            node = __float_as_int(hi.w);
+                        }
+                        walking = pending < 0 && node != end;
+                        alive = (node != end) || pending >= 0;
+                    }
+                } while (__popcll(__ballot(walking)) >= (minWalk > 1 ? minWalk : 1));
             }
         }
         // ---- triangle tests of the parked lanes ----
