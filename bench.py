@@ -1,51 +1,48 @@
 #!/usr/bin/env python3
-"""bench.py — Mrays/s and ms/frame of the hot path at BASELINE.json's headline configuration.
+"""bench.py — Mrays/s and ms/frame of the hot path on the scene BOTH north_star targets name: BASELINE config 3.
 
-Workload (config.workload): BASELINE config 2 — Cornell box stand-in (18 444 triangles; the reference's scene assets
-are absent), 1920x1080, 8 bounces, 1 spp per frame, `pathTrace` semantics.  A "step" is one frame: step s
-renders Sobol row `looper = s` with `iter = 0` (the reference app resets `iteration` every frame), into
-device-resident image buffers.
+Default workload (`config.workload`): teapots stand-in (100 364 triangles; the reference's assets are absent),
+1920x1080, 8 bounces, 1 spp per frame, `pathTrace` semantics, in the structure config 3 names — the wavefront pipeline with
+stream compaction and the material sort (`--mode wavefront_sort2`: three sub-frame pipelines on three streams).
+It replaces the `printf("PT runtime ...")` of /root/reference/src/pathtrace.cu:352-377.  A "step" is one frame: step s renders
+Sobol row `looper = s` with `iter = 0` (the reference app resets `iteration` every frame) into device-resident
+images.  The SAME default runs at every N, so the driver's BENCH line and the N = 1 point of its SCALE curve are one workload.
 
 N = 1:  one process, one GPU, frame layout.
 N > 1:  one rank per GPU over RCCL.  `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the ranks itself:
         before torch or HIP is touched it runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
         process, relays its output and exits with its code; launched by torch.distributed.run it is simply a rank.
         The frame is cut into 64x64 tiles, tile t → rank t % N (strong scaling: the frame is fixed, per-GPU work shrinks).
-        Each rank traces its tiles into packed tile buffers; the finished tiles are exchanged with ONE RCCL all-gather per
-        image per frame (all_gather_into_tensor over xGMI) and re-assembled with rdh_untile — all inside the timed region.
+        The headline runs the PRODUCT's collective: `rdh_path_trace_gathered` (library RCCL — ncclAllGather on the context's
+        stream, then the un-tile kernel: what a C++ Radish host calls), whole-frame images on every rank.
+        `collective_cross_check` re-times the same frames with torch.distributed's all_gather_into_tensor (same RCCL underneath).
+        If the library's communicator cannot be created (e.g. the gloo rehearsal on a one-GPU box) the torch path IS the
+        headline and `config.collective` says so with the reason — never silently.
 
-Frames in flight: `value` and `ms_per_step` are ALWAYS measured with ONE frame in flight (F = 1: frame s+1 is issued when frame
-s has been enqueued on the same stream; ms_per_step is then a frame latency as well as a rate), at every N, so the scaling
-curve compares like with like.  A second, labelled figure `pipelined` re-times the same K frames with F = max(3, N) frames in
-flight (each on its own stream and buffers, persistent grids divided by F so the slots together fill the GPU once; on one GPU
-F = 3 measured best: 2.66 ms against 2.80 at F = 2 and 3.04 at F = 4): that one is throughput only.
-`--frames-in-flight F` overrides the headline's F (then `config.frames_in_flight` says so).
-Frames in flight need HARDWARE queues of their own: ROCm gives a process 4 by default and deals further streams onto them round
-robin, so two contexts (three streams each) can land on one queue and run one after the other (measured: F = 2 at 4.71 ms per
-frame instead of 2.80).  bench.py therefore sets GPU_MAX_HW_QUEUES=16 before the HIP runtime starts, unless the caller has set it.
+Frames in flight: `value` / `ms_per_step` are ALWAYS one frame in flight (F = 1), at every N.  `pipelined` re-times the same K
+frames with F = max(3, N) frames in flight (throughput only, labelled).  GPU_MAX_HW_QUEUES=16 is set before HIP starts
+(contexts on separate streams need hardware queues of their own).
 
 value = (closest-hit + any-hit rays actually traced in the K timed frames, all ranks) / (max-over-ranks wall time).
-Ray counts are exact device counters taken in an untimed pass over the same Sobol rows (the counters cost atomics,
-so the timed pass runs without them; the rays traced are identical).
+Ray counts are exact device counters taken in an untimed pass over the same Sobol rows.
 
-roofline: the dominant kernel is the one that traverses (k_pt_persistent by default; k_wf_trace in wavefront mode,
-k_path_trace_mega in megakernel mode).
-`achieved` = algorithmic bytes ÷ the hipEvent-measured duration of its launches during the timed steps, with
-  B = 40·closestRays + 28·anyRays + 32·nodeVisits + 36·triTests + 64·closestHits          
-(ray in 24 B + hit record 16 B / occlusion flag 4 B; 32 B per box step; 36 B per triangle test; 64 B of normals, uvs and
-material id per found hit), against the 8.0 TB/s HBM3E peak.
-`roofline.traversal_only` (N = 1): north_star's 70 % target is "during BVH traversal", so the walk-only kernel
-(k_walk_persistent, device/kernels_walk.h) is timed in this same run on the ray lists of the warm-up frame itself (every
-closest-hit ray and every occlusion segment of frame looper = warmup, dumped once, untimed), with the algorithmic bytes of
-exactly those rays.
-`roofline.traffic`: HBM-side bytes per launch from PMC counters cannot be read inside the run; when profiles/hbm_traffic.json
-holds the figure of a `rocprofv3 --pmc` pass of this exact workload it is carried with `traffic_source: "replayed ..."`.
+roofline: B = 40·closestRays + 28·anyRays + 32·nodeVisits + 36·triTests + 64·closestHits algorithmic bytes.
+  * persistent / mega / one-pipeline wavefront: `achieved` = B per launch ÷ hipEvent-measured launch duration (RDH_PT_PROFILE).
+  * wavefront with sub-frames (the default): the three pipelines' launches overlap BY DESIGN, so no single launch time means
+    anything; `achieved` = B per FRAME ÷ the hipEvent span of the frame (one event pair, before the fork → after the join, on the
+    context's stream), dominant kernel named k_wf_trace, `launches` = frames, `span` = "frame".
+  * `traversal_only` (N = 1): k_walk_persistent timed on the warm-up frame's own ray lists; next to its §8(d) fraction it carries
+    `l1_request_frac` = box steps/s ÷ the measured ceiling of this record layout (two L1 requests per lane and step: 304 G box
+    steps/s, scripts/micro/gather_modes, profiles/r01_c_micro_gather_modes.txt) — the honest ceiling: these scenes live in
+    L2 / Infinity Cache, HBM-side traffic is a small fraction of B (`traffic`, replayed from the committed PMC passes).
+cpu_baseline (rank 0, N = 1): §8d's denominator — the oracle's intersect / testOcclusion over a strided sample of the SAME ray
+lists, one pinned thread, best of 3; beside it the oracle's whole pathTrace (all cores: the full frame = the parity reference of
+`parity_check`; one thread: every 8th pixel).  A parity failure exits non-zero WITHOUT printing a performance line.
+`configs` (N = 1): short sub-records of BASELINE configs 2, 4 and 5's scene — {ms_per_step, mrays_s, frac, parity_sample_ok},
+each checked against the oracle on >= 20 000 pixels.
 
-cpu_baseline (rank 0, N = 1 only): §8d's denominator — the oracle's DevScene::intersect / testOcclusion (restating
-src/intersections.h + src/scene.h:262-334) over a strided sample of the SAME dumped ray lists, one thread pinned to a core,
-best of 3 → `value`; beside it the oracle's whole pathTrace of the frame, one thread (`whole_path_trace`) and all cores
-(`all_cores`), whose image is a full-frame bit-exact parity check of the timed configuration (`parity_check`).  A parity
-failure makes bench.py exit non-zero WITHOUT printing a performance line.
+`--workload restir`: ReSTIR DI (config 4 at N = 1; config 5 — the 1-M-triangle scene at 4K, 128-px ownership tiles, partitioned
+G-buffer — at N > 1) through the same self-launch, with the library's gathered entries.
 """
 import argparse
 import json
@@ -59,10 +56,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L1_BOX_STEP_CEILING_G = 304.0  # box steps/s the vector L1s can serve with 32-B NodeRec (2 requests per lane and step), chip-wide
+RESTIR_PX_BYTES = 2384  # per ReSTIR pixel, both passes, excluding its two rays
 
 
 def algorithmic_bytes(c):
     return (40 * c["closestRays"] + 28 * c["anyRays"] + 32 * c["nodeVisits"] + 36 * c["triTests"] + 64 * c["closestHits"])
+
+
+MODES = ["mega", "wavefront", "wavefront_sort", "wavefront2", "wavefront_sort2", "persistent"]
 
 
 def parse_args():
@@ -70,17 +72,18 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--workload", default=os.environ.get("RADISH_BENCH_WORKLOAD", "pathtrace"), choices=["pathtrace", "restir"])
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "persistent"),
-                    choices=["mega", "wavefront", "wavefront_sort", "wavefront2", "wavefront_sort2", "persistent"],
-                    help="wavefront2 / wavefront_sort2: the wavefront pipeline as three sub-frames on three streams (RDH_PT_WF_SUBFRAMES)")
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_small", "teapots", "teapots_lights", "teasets_1m"])
-    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--mode", default=os.environ.get("RADISH_BENCH_MODE", "auto"), choices=["auto"] + MODES,
+                    help="auto = config 3's named structure, wavefront_sort2 (wavefront + compaction + material sort, three sub-frames)")
+    ap.add_argument("--scene", default=None, choices=["cornell", "cornell_small", "teapots", "teapots_lights", "teasets_1m"])
+    ap.add_argument("--tile", type=int, default=None, help="ownership tile edge (default 64; restir at N > 1: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traversal-only", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sub-records of configs 2, 4 and 5")
     ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RADISH_FRAMES_IN_FLIGHT", "1")),
                     help="frames in flight of the HEADLINE measurement (default 1 at every N)")
     ap.add_argument("--master-port", type=int, default=int(os.environ.get("RADISH_MASTER_PORT", "29533")))
@@ -102,6 +105,180 @@ def self_launch(args):
     return proc.wait()
 
 
+def make_scene(name):
+    from radish_pt_amd import scenes
+
+    return {"cornell": scenes.cornell, "cornell_small": lambda: scenes.cornell(segments=16, bands=12),
+            "teapots": scenes.teapots, "teapots_lights": lambda: scenes.teapots(emissive_grid=(16, 32)),
+            # stand-in for BASELINE config 5's "camera and tea sets" (asset absent): the teapots scene re-tessellated to ~1.0 M tris
+            "teasets_1m": lambda: scenes.teapots(segments=200, bands=156, emissive_grid=(16, 32))}[name]()
+
+
+def make_camera(name, W, H):
+    from radish_pt_amd import scenes
+
+    return scenes.cornell_camera(W, H) if name.startswith("cornell") else scenes.teapots_camera(W, H)
+
+
+def mode_flags(api, mode):
+    return {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
+            "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,
+            "wavefront2": api.RDH_PT_WAVEFRONT | api.RDH_PT_WF_SUBFRAMES,
+            "wavefront_sort2": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES,
+            "persistent": api.RDH_PT_PERSISTENT}[mode]
+
+
+def dominant_kernel(api, flags):
+    return ("k_wf_trace" if flags & api.RDH_PT_WAVEFRONT else "k_pt_persistent" if flags & api.RDH_PT_PERSISTENT else "k_path_trace_mega")
+
+
+def bit_equal(a, b):
+    import numpy as np
+
+    return bool(np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# sub-records of the other BASELINE configs (N = 1 only): short, each with an oracle sample of >= 20 000 pixels
+# ---------------------------------------------------------------------------------------------------------------------------
+def sub_path_trace(torch, np, api, dev, scene_name, W, H, depth, mode, K, warm, stride, label):
+    """configs 2 / 5: pathTrace of `scene_name` in structure `mode`; parity on every `stride`-th pixel of the first timed frame."""
+    from oracle import pyoracle
+
+    sd = make_scene(scene_name)
+    cam = make_camera(scene_name, W, H)
+    flags = mode_flags(api, mode)
+    ctx = api.Context(dev.index)
+    ctx.upload_scene(sd)
+    ctx.set_camera(cam)
+    d = torch.zeros(W * H, 3, device=dev)
+    i = torch.zeros(W * H, 3, device=dev)
+    for s in range(warm):
+        ctx.path_trace(d, i, 0, s, depth, flags)
+    ctx.counters_reset()
+    for s in range(warm, warm + K):
+        ctx.path_trace(d, i, 0, s, depth, flags | api.RDH_PT_COUNT)
+    c = ctx.counters()
+    ctx.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warm, warm + K):
+        ctx.path_trace(d, i, 0, s, depth, flags | api.RDH_PT_PROFILE)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    k_ms, k_n = ctx.profile_read()
+    rays = c["closestRays"] + c["anyRays"]
+    alg = algorithmic_bytes(c)
+    frac = alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None
+    # parity sample: the oracle on every stride-th pixel of frame looper = warm
+    ctx.path_trace(d, i, 0, warm, depth, flags)
+    ctx.synchronize()
+    g_d, g_i = d.cpu().numpy(), i.cpu().numpy()
+    r_d, r_i = np.zeros((W * H, 3), np.float32), np.zeros((W * H, 3), np.float32)
+    n_t = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    import threading
+
+    hs = [pyoracle.OracleScene(sd) for _ in range(n_t)]
+    th = [threading.Thread(target=hs[t].path_trace, args=(cam, r_d, r_i, 0, warm, depth), kwargs={"pix": (t * stride, W * H, n_t * stride)})
+          for t in range(n_t)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    sel = np.arange(0, W * H, stride)
+    ok = bit_equal(g_d[sel], r_d[sel]) and bit_equal(g_i[sel], r_i[sel])
+    ctx.close()
+    return {"workload": label, "mode": mode, "ms_per_step": round(el / K * 1e3, 4), "mrays_s": round(rays / el / 1e6, 1),
+            "frac": None if frac is None else round(frac, 4), "frac_is": "algorithmic bytes / hipEvent time of %s (%d launches) / 8 TB/s" % (dominant_kernel(api, flags), k_n),
+            "rays_per_frame": rays / K, "parity_sample_ok": ok, "parity_sample_pixels": int(len(sel))}
+
+
+def sub_restir(torch, np, api, dev, W, H, K, num_spatial=5):
+    """config 4: teapots + 1 024 emissive triangles, ReSTIR DI M = 32, temporal + spatial, split pass 1; a frame = G-buffer + ReSTIR,
+    blocking after each as in the reference's runCuda (main.cpp:183-200).  Parity: the same scene and settings at 208x112 (23 296
+    px), two frames (temporal reuse active in the second), image bit-equal to the oracle's."""
+    from oracle import pyoracle
+    from radish_pt_amd import layouts as L
+
+    sd = make_scene("teapots_lights")
+    cam = make_camera("teapots_lights", W, H)
+    ctx = api.Context(dev.index)
+    ctx.upload_scene(sd)
+    ctx.set_camera(cam)
+    gb = api.GBuffer()
+    gb.create(W, H, dev.index)
+    img = torch.zeros(W * H, 3, device=dev)
+    ctx.restir_init()
+
+    def frame(f, flags=0):
+        ctx.set_camera(cam)
+        ctx.gbuffer_render(gb.c_struct(cam_fallback=cam), 0)
+        ctx.synchronize()
+        t_g = ctx.last_kernel_ms()
+        ctx.restir_direct(img, 0, f, gb.c_struct(cam), 3, num_spatial=num_spatial, flags=flags)
+        ctx.synchronize()
+        t_r = ctx.last_kernel_ms()
+        gb.update(cam)
+        return t_g, t_r
+
+    for f in range(3):
+        frame(f)
+    ctx.counters_reset()
+    frame(3, api.RDH_PT_COUNT)
+    c = ctx.counters()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tg = tr = 0.0
+    for f in range(4, 4 + K):
+        a, b = frame(f)
+        tg += a
+        tr += b
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rays = c["closestRays"] + c["anyRays"]
+    ray_bytes = algorithmic_bytes(c)
+    ctx.restir_free()
+    ctx.close()
+    # parity at 208x112
+    w2, h2 = 208, 112
+    cam2 = make_camera("teapots_lights", w2, h2)
+    ctx2 = api.Context(dev.index)
+    ctx2.upload_scene(sd)
+    ctx2.set_camera(cam2)
+    o = pyoracle.OracleScene(sd)
+    gbo = pyoracle.GBufferHost(w2, h2)
+    gbg = api.GBuffer()
+    gbg.create(w2, h2, dev.index)
+    res = [np.zeros(w2 * h2, L.RESERVOIR_DTYPE) for _ in range(3)]
+    img2 = torch.zeros(w2 * h2, 3, device=dev)
+    ctx2.restir_init()
+    ok = True
+    for f in range(2):
+        o.gbuffer_render(cam2, gbo)
+        ref = np.zeros((w2 * h2, 3), np.float32)
+        o.restir_direct(cam2, ref, 0, f, res[0], res[1], res[2], gbo, f == 0, 3, 1, num_spatial, 32)
+        res[0], res[1] = res[1], res[0]  # restir.cu:221
+        gbo.update(cam2)
+        ctx2.gbuffer_render(gbg.c_struct(cam_fallback=cam2), 0)
+        ctx2.restir_direct(img2, 0, f, gbg.c_struct(cam2), 3, num_spatial=num_spatial)
+        ctx2.synchronize()
+        gbg.update(cam2)
+        ok = ok and bit_equal(img2.cpu().numpy(), ref)
+    ctx2.restir_free()
+    ctx2.close()
+    k_s = tr / K * 1e-3
+    return {"workload": f"teapots + 1024 emissive tris ({sd.num_prims} tris), {W}x{H}, ReSTIR DI M=32, temporal + {num_spatial} spatial, split pass 1",
+            "ms_per_step": round(el / K * 1e3, 4), "ms_gbuffer_kernels": round(tg / K, 4), "ms_restir_kernels": round(tr / K, 4),
+            "mrays_s": round(rays / (el / K) / 1e6, 1), "rays_per_frame": rays,
+            "frac": round((ray_bytes + RESTIR_PX_BYTES * W * H) / k_s / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_rays_only": round(ray_bytes / k_s / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_is": "SURVEY 8d: (ray bytes + 2 384 B per pixel) / hipEvent time of the ReSTIR kernels / 8 TB/s; the 1 920 B/px of light-table "
+                       "reads come from LDS in this design, so frac_rays_only (the two walks' bytes alone over the same time) is the physical figure",
+            "parity_sample_ok": ok, "parity_sample_pixels": w2 * h2 * 2,
+            "parity_sample": f"same scene and settings at {w2}x{h2}, frames 0 and 1, image bit-equal to the oracle"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime starts (children of self_launch inherit it)
@@ -111,13 +288,14 @@ def main():
     import numpy as np
     import torch
 
-    from radish_pt_amd import api, scenes
+    from radish_pt_amd import api
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
 
@@ -137,49 +315,103 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", dev_index)
 
-    W, H, depth = args.width, args.height, args.depth
-    sd = {"cornell": scenes.cornell, "cornell_small": lambda: scenes.cornell(segments=16, bands=12),
-          "teapots": scenes.teapots, "teapots_lights": lambda: scenes.teapots(emissive_grid=(16, 32)),
-          # stand-in for BASELINE config 5's "camera and tea sets" (asset absent): the teapots scene re-tessellated to ~1.0 M tris
-          "teasets_1m": lambda: scenes.teapots(segments=200, bands=156, emissive_grid=(16, 32))}[args.scene]()
-    cam = scenes.cornell_camera(W, H) if args.scene.startswith("cornell") else scenes.teapots_camera(W, H)
-    flags = {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
-             "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,
-             "wavefront2": api.RDH_PT_WAVEFRONT | api.RDH_PT_WF_SUBFRAMES,
-             "wavefront_sort2": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES,
-             "persistent": api.RDH_PT_PERSISTENT}[args.mode]
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def agree(ok):
+        """True only if every rank says True (the ranks must take the same branch around collectives)."""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+
+    def share_unique_id():
+        """rank 0's ncclUniqueId for the library's communicator, handed to every rank over torch.distributed's store"""
+        box = [api.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    if args.workload == "restir":
+        rc = run_restir(args, torch, np, api, dist, dev, world, rank, backend, barrier, agree, share_unique_id)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(rc)
+
+    W, H, depth = args.width or 1920, args.height or 1080, args.depth
+    scene_name = args.scene or "teapots"
+    tile = args.tile or 64
+    mode = args.mode
+    mode_choice = None
+    if mode == "auto":
+        mode = "wavefront_sort2"
+        mode_choice = ("auto -> wavefront_sort2: BASELINE config 3's named structure (material-sorted wavefront + stream compaction; three "
+                       "sub-frame pipelines); on this scene it is also the fastest structure but for its own unsorted form (DESIGN §6)")
+    sd = make_scene(scene_name)
+    cam = make_camera(scene_name, W, H)
+    flags = mode_flags(api, mode)
+    subframes = bool(flags & api.RDH_PT_WF_SUBFRAMES)
     K, Wm = args.steps, args.warmup
+
+    # ---- the library's own communicator (headline collective at N > 1) ----
+    lib_comm_reason = None
 
     class Slot:
         """One frame in flight: its own context (stream, persistent-kernel workspace) and its own image buffers, so consecutive
         frames are independent (iter = 0: each frame overwrites its images)."""
 
-        def __init__(self, share):
+        def __init__(self, share, lib_comm):
+            nonlocal lib_comm_reason
             self.stream = torch.cuda.Stream(device=dev)
+            self.lib_comm = False
             with torch.cuda.stream(self.stream):
                 self.ctx = api.Context(dev.index)  # binds to the current torch stream = self.stream
                 self.ctx.upload_scene(sd)
                 self.ctx.set_camera(cam)
-                self.ctx.set_partition(rank, world, args.tile)
+                self.ctx.set_partition(rank, world, tile)
                 self.ctx.set_occupancy_share(share)
                 if world == 1:
                     self.direct = torch.zeros(W * H, 3, device=dev)
                     self.indirect = torch.zeros(W * H, 3, device=dev)
                 else:
-                    shard = self.ctx.tiles_per_rank() * args.tile * args.tile
+                    shard = self.ctx.tiles_per_rank() * tile * tile
                     self.direct = torch.zeros(shard, 3, device=dev)
                     self.indirect = torch.zeros(shard, 3, device=dev)
                     self.gath_d = torch.zeros(world * shard, 3, device=dev)
                     self.gath_i = torch.zeros(world * shard, 3, device=dev)
                     self.frame_d = torch.zeros(W * H, 3, device=dev)
                     self.frame_i = torch.zeros(W * H, 3, device=dev)
+            if world > 1 and lib_comm:
+                ok, why = True, None
+                try:
+                    uid = share_unique_id()
+                    with torch.cuda.stream(self.stream):
+                        self.ctx.comm_init(uid, rank, world)
+                except Exception as e:  # RCCL refuses two ranks on one device (the gloo rehearsal), or is not loadable
+                    ok, why = False, f"{type(e).__name__}: {e}"
+                if agree(ok):
+                    self.lib_comm = True
+                else:
+                    lib_comm_reason = why or "another rank could not create the library's communicator"
+                    if ok:
+                        self.ctx.comm_destroy()
+                        self.ctx.set_partition(rank, world, tile)
 
-        def step(self, s, f, comm_stream=None):
-            """One frame.  comm_stream None (the headline, F = 1): render, all-gather and un-tile on this slot's stream.
-            With several frames in flight every slot's collectives are issued on ONE shared stream, in frame order — the same
-            order on every rank, exactly as in the headline — and only the rendering overlaps."""
+        def step(self, s, f, comm_stream=None, use_lib=True):
+            """One frame.  Library collective (the headline): rdh_path_trace_gathered — pack, render this rank's tiles, two
+            ncclAllGather on the context's stream, un-tile.  torch collective: render into packed tiles, two all_gather_into_tensor,
+            rdh_untile; with several frames in flight every slot's torch collectives are issued on ONE shared stream, in frame
+            order — the same order on every rank — and only the rendering overlaps."""
+            looper = s % api.SOBOL_SAMPLE_NUM
             with torch.cuda.stream(self.stream):
-                self.ctx.path_trace(self.direct, self.indirect, 0, s % api.SOBOL_SAMPLE_NUM, depth, f)
+                if world > 1 and self.lib_comm and use_lib and comm_stream is None:
+                    self.ctx.path_trace_gathered(self.frame_d, self.frame_i, 0, looper, depth, f)
+                    return
+                self.ctx.path_trace(self.direct, self.indirect, 0, looper, depth, f)
                 if world > 1 and comm_stream is None:
                     dist.all_gather_into_tensor(self.gath_d, self.direct)
                     dist.all_gather_into_tensor(self.gath_i, self.indirect)
@@ -197,19 +429,14 @@ def main():
                     self.ctx.untile(self.gath_d, self.frame_d)
                     self.ctx.untile(self.gath_i, self.frame_i)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def measure(F):
+    def measure(F, lib_comm, slots=None, use_lib=True):
         """Warm up, count, then time exactly K frames with F frames in flight.  Returns a dict of this rank's figures."""
-        slots = [Slot(F) for _ in range(F)]
+        if slots is None:
+            slots = [Slot(F, lib_comm) for _ in range(F)]
         comm_stream = torch.cuda.Stream(device=dev) if (F > 1 and world > 1) else None
         torch.cuda.synchronize()
         for s in range(Wm):
-            slots[s % F].step(s, flags, comm_stream)
+            slots[s % F].step(s, flags, comm_stream, use_lib)
         torch.cuda.synchronize()
         for sl in slots:
             sl.ctx.counters_reset()
@@ -227,7 +454,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for s in range(Wm, Wm + K):
-            slots[s % F].step(s, flags | api.RDH_PT_PROFILE, comm_stream)
+            slots[s % F].step(s, flags | api.RDH_PT_PROFILE, comm_stream, use_lib)
         barrier()
         elapsed = time.perf_counter() - t0
         trace_ms, trace_launches = 0.0, 0
@@ -248,15 +475,21 @@ def main():
                 "trace_launches": trace_launches}
 
     F = max(1, args.frames_in_flight)
-    m = measure(F)
+    m = measure(F, lib_comm=(F == 1))
+    lib_headline = world > 1 and all(sl.lib_comm for sl in m["slots"])
+    cross = None
+    if lib_headline:  # the same frames through torch.distributed's collectives, on the same contexts: a cross-check of the headline
+        mc = measure(F, False, slots=m["slots"], use_lib=False)
+        cross = {"collective": "torch.distributed all_gather_into_tensor + rdh_untile", "value": round(mc["rays_total"] / mc["elapsed"] / 1e6, 3),
+                 "unit": "Mrays/s", "ms_per_step": round(mc["elapsed"] / K * 1e3, 4)}
     pipelined = None
     if not args.no_pipelined and F == 1:
         Fp = min(8, max(3, world))
-        mp_ = measure(Fp)
+        mp_ = measure(Fp, False)
         pipelined = {"frames_in_flight": Fp, "value": round(mp_["rays_total"] / mp_["elapsed"] / 1e6, 3), "unit": "Mrays/s",
                      "ms_per_step": round(mp_["elapsed"] / K * 1e3, 4),
                      "note": "throughput with several frames in flight per GPU (each on its own stream, persistent grids divided "
-                             "by F); not a frame latency, not the headline"}
+                             "by F" + ("; torch.distributed collectives on one shared stream" if world > 1 else "") + "); not a frame latency, not the headline"}
         for sl in mp_["slots"]:
             sl.ctx.close()
     slots = m["slots"]
@@ -268,43 +501,57 @@ def main():
     rc = 0
     if rank == 0:
         mrays = rays_total / elapsed / 1e6
-        launches = max(trace_launches, 1)
         alg_bytes = algorithmic_bytes(counters)  # rank 0's launches
-        # per-launch figures only mean something when launches do not overlap (F = 1)
-        # (… and the two-pipeline wavefront modes are not profiled per launch: their launches overlap by design)
-        achieved = (alg_bytes / launches) / (trace_ms / launches * 1e-3) / 1e9 if (trace_ms > 0 and F == 1) else None
+        # per-launch (or, with sub-frames, per-frame-span) figures only mean something when FRAMES do not overlap (F = 1)
+        have = trace_ms > 0 and trace_launches > 0 and F == 1
+        achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if have else None
         traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(pmc_path) and world == 1 and F == 1:  # the PMC figure is per launch of the one-GPU workload
+        if os.path.exists(pmc_path) and world == 1 and F == 1:  # the PMC figure is per launch / per frame of the one-GPU workload
             try:
                 with open(pmc_path) as fh:
                     pj = json.load(fh)
-                traffic = pj.get(f"{args.scene}_{args.mode}_{W}x{H}_d{depth}_bytes_per_launch")
+                traffic = pj.get(f"{scene_name}_{mode}_{W}x{H}_d{depth}_bytes_per_launch")
                 if traffic is not None:
-                    traffic_source = ("replayed from profiles/hbm_traffic.json — " + str(pj.get("source", "rocprofv3 --pmc pass of this workload"))
+                    traffic_source = ("replayed from profiles/hbm_traffic.json — " + str(pj.get(f"{scene_name}_{mode}_source", pj.get("source", "rocprofv3 --pmc pass of this workload")))
                                       + "; PMC counters cannot be read inside this run")
             except Exception:
                 traffic = None
+        kern = dominant_kernel(api, flags)
+        roof = {"bound": "hbm", "binds": "l1-request/latency",
+                "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "bound_note": "the contract's figure: algorithmic bytes per second against the HBM3E peak.  The scene is L2 / Infinity-Cache "
+                              "resident (traffic << algorithmic bytes), so what physically binds is the vector L1 (request rate and miss "
+                              "handling) together with VALU issue: see traversal_only.l1_request_frac (DESIGN.md §6-7)",
+                "kernel": kern}
+        if subframes:
+            roof.update({"span": "frame", "launches": trace_launches, "avg_launch_ms": round(trace_ms / max(trace_launches, 1), 5),
+                         "algorithmic_bytes_per_launch": alg_bytes / max(trace_launches, 1) if have else None,
+                         "span_note": "three sub-frame pipelines on three streams: their launches overlap by design, so the timed unit is the FRAME "
+                                      "(one hipEvent pair on the context's stream, before the fork -> after the join); `launches` counts frames, "
+                                      "`algorithmic_bytes_per_launch` is per frame; rocprofv3's per-kernel table of the same command is in profiles/"})
+        else:
+            roof.update({"span": "launch", "launches": trace_launches, "avg_launch_ms": round(trace_ms / max(trace_launches, 1), 5),
+                         "algorithmic_bytes_per_launch": alg_bytes / trace_launches if have else None})
         out = {
             "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "strong",  # the frame (total work) is fixed; per-GPU work shrinks with N
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} stand-in ({sd.num_prims} tris), {W}x{H}, {depth} bounces, 1 spp/frame, "
-                                   f"pathTrace ({args.mode}), tile-partitioned x{world}",
-                       "rays_per_frame": rays_total / K, "mode": args.mode, "parallelism": f"tile{args.tile}x{world}",
+            "config": {"workload": f"{scene_name} stand-in ({sd.num_prims} tris), {W}x{H}, {depth} bounces, 1 spp/frame, "
+                                   f"pathTrace ({mode}), tile-partitioned x{world}",
+                       "baseline_config": 3 if scene_name == "teapots" else None,
+                       "rays_per_frame": rays_total / K, "mode": mode, "mode_choice": mode_choice, "parallelism": f"tile{tile}x{world}",
                        "frames_in_flight": F,
+                       "collective": (None if world == 1 else
+                                      "library RCCL: rdh_path_trace_gathered (ncclAllGather on the context's stream + k_untile)" if lib_headline else
+                                      f"torch.distributed all_gather_into_tensor + rdh_untile — the library's communicator was not used: {lib_comm_reason or 'frames in flight > 1'}"),
                        "value_is": f"F = {F} frame(s) in flight: every frame is enqueued after the previous one on one stream per GPU"},
-            "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "bound_note": "algorithmic bytes per second against the HBM3E peak; the scene is L2 / Infinity-Cache resident, "
-                                       "so the binding units are the L1 request rate and VALU issue (DESIGN.md §6-7)",
-                         "kernel": ("k_wf_trace" if flags & api.RDH_PT_WAVEFRONT else
-                                    "k_pt_persistent" if flags & api.RDH_PT_PERSISTENT else "k_path_trace_mega"),
-                         "launches": trace_launches, "avg_launch_ms": round(trace_ms / launches, 5),
-                         "algorithmic_bytes_per_launch": alg_bytes / launches},
+            "roofline": roof,
         }
+        if cross is not None:
+            out["collective_cross_check"] = cross
         if pipelined is not None:
             out["pipelined"] = pipelined
 
@@ -335,11 +582,16 @@ def main():
                 t_ms /= reps
             wbytes = algorithmic_bytes(wc)
             wach = wbytes / (t_ms * 1e-3) / 1e9
+            steps_g = wc["nodeVisits"] / (t_ms * 1e-3) / 1e9
             out["roofline"]["traversal_only"] = {
                 "kernel": "k_walk_persistent (closest-hit list, then any-hit list)", "rays": int(closest.shape[0] + segs.shape[0]),
                 "ms": round(t_ms, 4), "algorithmic_bytes": wbytes, "achieved": round(wach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(wach / HBM_PEAK_GBS, 4), "mrays_per_s": round((closest.shape[0] + segs.shape[0]) / (t_ms * 1e-3) / 1e6, 1),
-                "box_steps_per_s_G": round(wc["nodeVisits"] / (t_ms * 1e-3) / 1e9, 1),
+                "box_steps_per_s_G": round(steps_g, 1),
+                "l1_request_frac": round(steps_g / L1_BOX_STEP_CEILING_G, 4), "l1_request_ceiling_G": L1_BOX_STEP_CEILING_G,
+                "l1_note": "box steps/s against what the 256 vector L1s can serve for this record layout (two requests per lane and step, "
+                           "27 ns per 64-lane request whatever its width: 304 G box steps/s, scripts/micro/gather_modes).  Of the two "
+                           "fractions this is the one with a physical ceiling at 1: the §8(d) byte figure has none while the nodes are served from cache",
                 "sample": f"every ray of frame looper={Wm} of this workload (dumped untimed), hipEvents on the context's stream, mean of {reps}",
             }
         if world == 1 and not args.no_cpu_baseline:
@@ -374,45 +626,47 @@ def main():
                 "sample": f"oracle DevScene::intersect / testOcclusion (traversal only) over every {stride_r}-th ray of the frame's own "
                           f"ray lists (looper {Wm}): {n_sample} rays, one pinned thread, best of 3 = {best:.2f} s",
             }
-            # ---- the oracle's whole pathTrace of the same frame (shading included), one thread: also the parity reference ----
+            # ---- the oracle's whole pathTrace of every 8th pixel of the same frame (shading included), one pinned thread ----
             o.reset_stats()
-            ref_d = np.zeros((W * H, 3), np.float32)
-            ref_i = np.zeros((W * H, 3), np.float32)
+            one_d = np.zeros((W * H, 3), np.float32)
+            one_i = np.zeros((W * H, 3), np.float32)
+            one_stride = 8
             tc = time.perf_counter()
-            o.path_trace(cam, ref_d, ref_i, 0, Wm, depth)
+            o.path_trace(cam, one_d, one_i, 0, Wm, depth, pix=(0, W * H, one_stride))
             cpu_s = time.perf_counter() - tc
             st = o.stats()
             cpu_rays = st["closestRays"] + st["anyRays"]
             out["cpu_baseline"]["whole_path_trace"] = {
                 "value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": 1,
-                "sample": f"oracle pathTrace on every pixel of the same {W}x{H} depth-{depth} frame (looper {Wm}): {cpu_rays} rays in {cpu_s:.1f} s"}
+                "sample": f"oracle pathTrace on every {one_stride}-th pixel of the same {W}x{H} depth-{depth} frame (looper {Wm}): {cpu_rays} rays in {cpu_s:.1f} s"}
             pin(full_affinity)
+            # ---- the whole frame on all cores: the parity reference ----
             import threading
 
             nthreads = max(1, min(16, len(full_affinity) if full_affinity else (os.cpu_count() or 1)))
-            all_equal = True
-            if nthreads > 1:
-                handles = [pyoracle.OracleScene(sd) for _ in range(nthreads)]
-                td, ti = np.zeros((W * H, 3), np.float32), np.zeros((W * H, 3), np.float32)
-                threads = [threading.Thread(target=handles[t].path_trace, args=(cam, td, ti, 0, Wm, depth),
-                                            kwargs={"pix": (t, W * H, nthreads)}) for t in range(nthreads)]
-                tc = time.perf_counter()
-                for th in threads:
-                    th.start()
-                for th in threads:
-                    th.join()
-                par_s = time.perf_counter() - tc
-                par_rays = sum(h.stats()["closestRays"] + h.stats()["anyRays"] for h in handles)
-                all_equal = bool(np.array_equal(td.view(np.uint32), ref_d.view(np.uint32)) and np.array_equal(ti.view(np.uint32), ref_i.view(np.uint32)))
-                out["cpu_baseline"]["all_cores"] = {"value": round(par_rays / par_s / 1e6, 4), "unit": "Mrays/s", "cores": nthreads,
-                                                    "bit_equal_to_one_thread": all_equal}
+            handles = [pyoracle.OracleScene(sd) for _ in range(nthreads)]
+            ref_d, ref_i = np.zeros((W * H, 3), np.float32), np.zeros((W * H, 3), np.float32)
+            threads = [threading.Thread(target=handles[t].path_trace, args=(cam, ref_d, ref_i, 0, Wm, depth),
+                                        kwargs={"pix": (t, W * H, nthreads)}) for t in range(nthreads)]
+            tc = time.perf_counter()
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            par_s = time.perf_counter() - tc
+            par_rays = sum(h.stats()["closestRays"] + h.stats()["anyRays"] for h in handles)
+            sel = np.arange(0, W * H, one_stride)
+            all_equal = bit_equal(one_d[sel], ref_d[sel]) and bit_equal(one_i[sel], ref_i[sel])
+            out["cpu_baseline"]["all_cores"] = {"value": round(par_rays / par_s / 1e6, 4), "unit": "Mrays/s", "cores": nthreads,
+                                                "sample": f"the whole frame: {par_rays} rays in {par_s:.1f} s",
+                                                "bit_equal_to_one_thread": all_equal}
             # parity check on the timed configuration: the whole GPU frame must equal the oracle's bit for bit
             with torch.cuda.stream(slots[0].stream):
                 ctx.path_trace(direct, indirect, 0, Wm, depth, flags)
             ctx.synchronize()
             g_d, g_i = direct.cpu().numpy(), indirect.cpu().numpy()
             bad = np.argwhere((g_d.view(np.uint32) != ref_d.view(np.uint32)) | (g_i.view(np.uint32) != ref_i.view(np.uint32)))
-            out["parity_check"] = {"pixels": int(W * H), "bit_exact": bool(len(bad) == 0)}
+            out["parity_check"] = {"pixels": int(W * H), "bit_exact": bool(len(bad) == 0), "against": "the CPU oracle's frame (all cores; one thread agrees on every 8th pixel)"}
             if len(bad) or not all_equal:
                 # a performance number for wrong pixels is worthless: report and fail, print no metric line
                 p = int(bad[0][0]) if len(bad) else -1
@@ -433,7 +687,7 @@ def main():
                 solo = api.Context(dev.index)
                 solo.upload_scene(sd)
                 solo.set_camera(cam)
-                solo.set_partition(0, 1, args.tile)
+                solo.set_partition(0, 1, tile)
                 solo_d = torch.zeros(W * H, 3, device=dev)
                 solo_i = torch.zeros(W * H, 3, device=dev)
                 solo.path_trace(solo_d, solo_i, 0, s_last % api.SOBOL_SAMPLE_NUM, depth, flags)
@@ -447,11 +701,32 @@ def main():
             if n_bad:
                 p = int(torch.nonzero(diff.any(dim=1))[0])
                 print(f"bench.py: PARITY FAILURE at {world} ranks — {n_bad} floats of the gathered frame differ from the one-rank frame; "
-                      f"first at pixel {p} (x={p % W}, y={p // W}, tile {(p // W) // args.tile * ((W + args.tile - 1) // args.tile) + (p % W) // args.tile})",
+                      f"first at pixel {p} (x={p % W}, y={p // W}, tile {(p // W) // tile * ((W + tile - 1) // tile) + (p % W) // tile})",
                       file=sys.stderr, flush=True)
                 rc = 3
         elif args.no_cpu_baseline:
             out["cpu_baseline"] = None
+
+        # ---- sub-records of the other BASELINE configs (N = 1) ----
+        if world == 1 and not args.no_configs and rc == 0:
+            for sl in slots:
+                sl.ctx.close()
+            slots = []
+            del direct, indirect, closest, segs
+            torch.cuda.empty_cache()
+            cfgs = {}
+            try:
+                cfgs["2"] = sub_path_trace(torch, np, api, dev, "cornell", 1920, 1080, 8, "persistent", 10, 3, 100,
+                                           "BASELINE config 2: Cornell stand-in (18 444 tris), 1920x1080, 8 bounces, one persistent launch per frame")
+                cfgs["4"] = sub_restir(torch, np, api, dev, 1920, 1080, 8)
+                cfgs["5_scene_one_gpu"] = sub_path_trace(torch, np, api, dev, "teasets_1m", 3840, 2160, 8, "persistent", 3, 3, 400,
+                                                         "BASELINE config 5's scene on ONE GPU: teapots re-tessellated to 999 436 tris, 3840x2160, 8 bounces, pathTrace")
+            except Exception as e:  # a sub-record must not cost the headline; say what happened
+                cfgs["error"] = f"{type(e).__name__}: {e}"
+            out["configs"] = cfgs
+            if any(isinstance(v, dict) and v.get("parity_sample_ok") is False for v in cfgs.values()):
+                print("bench.py: PARITY FAILURE in a config sub-record: " + json.dumps(cfgs), file=sys.stderr, flush=True)
+                rc = 3
         if rc == 0:
             print(json.dumps(out), flush=True)
     if world > 1:
@@ -460,6 +735,140 @@ def main():
     for sl in slots:
         sl.ctx.close()
     sys.exit(rc)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# --workload restir: ReSTIR DI through the library's gathered entries (config 4 at N = 1; config 5 at N > 1)
+# ---------------------------------------------------------------------------------------------------------------------------
+def run_restir(args, torch, np, api, dist, dev, world, rank, backend, barrier, agree, share_unique_id):
+    multi = world > 1
+    scene_name = args.scene or ("teasets_1m" if multi else "teapots_lights")
+    W = args.width or (3840 if multi else 1920)
+    H = args.height or (2160 if multi else 1080)
+    # ReSTIR's pass 1 over-computes an 8-px apron around a rank's tiles (spatial radius 5): (tile + 16)^2 / tile^2 pixels — +56 % at
+    # 64-px tiles, +27 % at 128; ownership granularity for ReSTIR is therefore 128 px (pathTrace keeps 64)
+    tile = args.tile or (128 if multi else 64)
+    K, Wm = args.steps, max(args.warmup, 2)
+    sd = make_scene(scene_name)
+    cam = make_camera(scene_name, W, H)
+    ctx = api.Context(dev.index)
+    ctx.upload_scene(sd)
+    ctx.set_camera(cam)
+    ctx.set_partition(rank, world, tile)
+    lib_comm, why = False, None
+    if multi:
+        ok = True
+        try:
+            ctx.comm_init(share_unique_id(), rank, world)
+        except Exception as e:
+            ok, why = False, f"{type(e).__name__}: {e}"
+        lib_comm = agree(ok)
+        if not lib_comm and ok:
+            ctx.comm_destroy()
+            ctx.set_partition(rank, world, tile)
+    gb = api.GBuffer()
+    gb.create(W, H, dev.index)
+    frame_img = torch.zeros(W * H, 3, device=dev)
+    n_local = W * H if not multi else ctx.tiles_per_rank() * tile * tile
+    img = torch.zeros(n_local, 3, device=dev)
+    packed9 = torch.zeros(n_local, 9, device=dev)
+    ctx.restir_init()
+
+    def gather(t):
+        if backend == "gloo":  # rehearsal: gloo moves host memory
+            h = t.cpu()
+            o = torch.empty(world * h.shape[0], *h.shape[1:], dtype=h.dtype)
+            dist.all_gather_into_tensor(o, h)
+            return o.to(dev)
+        o = torch.empty(world * t.shape[0], *t.shape[1:], dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(o, t)
+        return o
+
+    def frame(f, flags=0):
+        """runCuda's sequence (main.cpp:183-200): G-buffer, ReSTIRDirect, G-buffer update — on N ranks with the exchanges."""
+        ctx.set_camera(cam)
+        g = gb.c_struct(cam_fallback=cam)
+        if not multi:
+            ctx.gbuffer_render(g, 0)
+            ctx.restir_direct(frame_img, 0, f, gb.c_struct(cam), 3, flags=flags)
+        elif lib_comm:
+            ctx.gbuffer_render(g, api.RDH_PT_PARTITION_GBUFFER)
+            ctx.gbuffer_exchange(g)
+            ctx.restir_direct_gathered(frame_img, 0, f, gb.c_struct(cam), 3, flags=flags)
+        else:
+            ctx.gbuffer_render(g, api.RDH_PT_PARTITION_GBUFFER)
+            ctx.gbuffer_exchange_pack(g, packed9)
+            ctx.synchronize()
+            ctx.gbuffer_exchange_unpack(g, gather(packed9))
+            ctx.restir_direct(img, 0, f, gb.c_struct(cam), 3, flags=flags)
+            ctx.synchronize()
+            ctx.untile(gather(img), frame_img)
+            ctx.restir_exchange_pack(packed9)
+            ctx.synchronize()
+            ctx.restir_exchange_unpack(gather(packed9))
+        ctx.synchronize()
+        gb.update(cam)
+
+    for f in range(Wm):
+        frame(f)
+    ctx.counters_reset()
+    frame(Wm, api.RDH_PT_COUNT)
+    c = ctx.counters()
+    barrier()
+    t0 = time.perf_counter()
+    for f in range(Wm + 1, Wm + 1 + K):
+        frame(f)
+    barrier()
+    el = time.perf_counter() - t0
+    rays_local = float(c["closestRays"] + c["anyRays"])
+    if multi:
+        st = torch.tensor([el, rays_local], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        mx, sm = st.clone(), st.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        el, rays = float(mx[0]), float(sm[1])
+    else:
+        rays = rays_local
+    rc = 0
+    parity = None
+    if multi:  # the partitioned frame against one rank rendering the same sequence alone (bit-equal image)
+        solo = api.Context(dev.index)
+        solo.upload_scene(sd)
+        solo.set_camera(cam)
+        gbs = api.GBuffer()
+        gbs.create(W, H, dev.index)
+        simg = torch.zeros(W * H, 3, device=dev)
+        solo.restir_init()
+        for f in range(Wm + 1 + K):
+            solo.set_camera(cam)
+            solo.gbuffer_render(gbs.c_struct(cam_fallback=cam), 0)
+            solo.restir_direct(simg, 0, f, gbs.c_struct(cam), 3)
+            solo.synchronize()
+            gbs.update(cam)
+        n_bad = int((simg.view(torch.int32) != frame_img.view(torch.int32)).sum())
+        parity = {"pixels": W * H, "bit_exact": n_bad == 0, "against": f"the same {Wm + 1 + K}-frame sequence rendered by this rank alone (whole frame)"}
+        solo.restir_free()
+        solo.close()
+        if n_bad:
+            print(f"bench.py: PARITY FAILURE (restir, {world} ranks): {n_bad} floats differ from the one-rank frame", file=sys.stderr, flush=True)
+            rc = 3
+    if rank == 0 and rc == 0:
+        out = {"metric": "Mrays/s", "value": round(rays / (el / K) / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
+               "ms_per_step": round(el / K * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": f"{scene_name} stand-in ({sd.num_prims} tris, {sd.num_lights} emissive), {W}x{H}, ReSTIR DI M=32, temporal "
+                                      f"(clamp 20) + 5 spatial, G-buffer + split pass 1 + pass 2 per frame, tile-partitioned x{world}",
+                          "baseline_config": 5 if multi else 4, "rays_per_frame": rays, "parallelism": f"tile{tile}x{world}",
+                          "apron": None if not multi else f"pass 1 over-computes an 8-px apron: +{((tile + 16) ** 2 / tile ** 2 - 1) * 100:.0f} % pixels at {tile}-px tiles",
+                          "collective": None if not multi else ("library RCCL: rdh_gbuffer_exchange + rdh_restir_direct_gathered" if lib_comm else
+                                                                f"torch.distributed (library communicator not used: {why})")},
+               "parity_check": parity, "cpu_baseline": None,
+               "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                            "note": "per-kernel figures of this workload: `configs.4` of the default bench line and profiles/"}}
+        print(json.dumps(out), flush=True)
+    ctx.restir_free()
+    ctx.close()
+    return rc
 
 
 if __name__ == "__main__":

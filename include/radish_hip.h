@@ -109,8 +109,10 @@ typedef struct rdh_counters {
 #define RDH_PT_WF_SMALL_LISTS 4096u /* wavefront only, for tests: the per-stage lists of literal-class rays hold 4 entries, so that the
                                   overflow path (such rays stay in the ordinary queues) runs */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
-#define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_wf_trace, or the megakernel)
-                                  with hipEvents on the context's stream; read with rdh_profile_read            */
+#define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_pt_persistent, k_wf_trace, or the megakernel)
+                                  with hipEvents on the context's stream; read with rdh_profile_read.  With
+                                  RDH_PT_WF_SUBFRAMES the pipelines' launches overlap by design: ONE pair brackets the whole
+                                  frame (before the fork to after the join) and rdh_profile_read counts frames            */
 
 /* ReSTIR reuse mask = ReservoirReuse (src/common.h:41-48) */
 #define RDH_REUSE_TEMPORAL 1
@@ -198,13 +200,24 @@ int rdh_gbuffer_exchange_unpack(rdh_ctx *ctx, const rdh_gbuffer *gb, const float
  *   rdh_restir_exchange          this rank's pre-spatial reservoirs of the frame just rendered → all-gather → every rank's
  *                                `last` reservoir buffer holds the whole frame (next frame's temporal reuse): 36 B/px
  *   rdh_restir_direct_gathered   ReSTIRDirect for N GPUs: whole-frame image in and out, includes rdh_restir_exchange
- *   rdh_gbuffer_exchange         pack → all-gather → unpack of the G-buffer records (see above)                              */
+ *   rdh_gbuffer_exchange         pack → all-gather → unpack of the G-buffer records (see above)
+ * ONE process driving n GPUs (the reference's host model: one process, one frame loop, /root/reference/src/main.cpp:71-116,
+ * :163-202; SURVEY §8e "single process ... one host thread + stream per device"):
+ *   rdh_comm_init_all            ctxs[i] (created on n DIFFERENT devices) becomes rank i of n: the n ncclCommInitRank calls are
+ *                                made inside one ncclGroupStart/End, so one host thread can create them (rdh_comm_init blocks
+ *                                until every rank has called it and therefore needs a thread or process per rank)
+ *   rdh_path_trace_gathered_all  rdh_path_trace_gathered for all n contexts from one thread: n renders enqueued on n streams,
+ *                                then per image ONE RCCL group with the n all-gathers, then n un-tile kernels.
+ *                                d_directFrames[i] / d_indirectFrames[i]: whole-frame images on ctxs[i]'s device.              */
 int rdh_comm_unique_id(void *id128);
 int rdh_comm_init(rdh_ctx *ctx, const void *id128, int rank, int world);
+int rdh_comm_init_all(rdh_ctx **ctxs, int n);
 int rdh_comm_destroy(rdh_ctx *ctx);
 int rdh_allgather_tiles(rdh_ctx *ctx, const float *d_packed, float *d_frame);
 int rdh_path_trace_gathered(rdh_ctx *ctx, float *d_directFrame, float *d_indirectFrame, int iter, int looper, int maxDepth,
                             uint32_t flags);
+int rdh_path_trace_gathered_all(rdh_ctx **ctxs, int n, float *const *d_directFrames, float *const *d_indirectFrames, int iter,
+                                int looper, int maxDepth, uint32_t flags);
 int rdh_restir_exchange(rdh_ctx *ctx);
 int rdh_restir_direct_gathered(rdh_ctx *ctx, float *d_directFrame, int iter, int looper, const rdh_gbuffer *gb,
                                const rdh_restir_params *params, uint32_t flags);

@@ -49,6 +49,7 @@ EXPORTS = [
     "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps", "rdh_debug_persist_phases",
     "rdh_gbuffer_exchange_pack", "rdh_gbuffer_exchange_unpack", "rdh_comm_unique_id", "rdh_comm_init", "rdh_comm_destroy",
     "rdh_dump_rays", "rdh_set_occupancy_share", "rdh_allgather_tiles", "rdh_path_trace_gathered", "rdh_restir_exchange", "rdh_restir_direct_gathered", "rdh_gbuffer_exchange",
+    "rdh_comm_init_all", "rdh_path_trace_gathered_all",
 ]
 
 
@@ -149,6 +150,8 @@ def lib():
             "rdh_comm_unique_id": ([vp], i32),
             "rdh_comm_init": ([vp, vp, i32, i32], i32),
             "rdh_comm_destroy": ([vp], i32),
+            "rdh_comm_init_all": ([C.POINTER(vp), i32], i32),
+            "rdh_path_trace_gathered_all": ([C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp), i32, i32, i32, u32], i32),
             "rdh_allgather_tiles": ([vp, vp, vp], i32),
             "rdh_path_trace_gathered": ([vp, vp, vp, i32, i32, i32, u32], i32),
             "rdh_restir_exchange": ([vp], i32),
@@ -381,6 +384,31 @@ class Context:
 
     def comm_destroy(self):
         self.check(lib().rdh_comm_destroy(self.h))
+
+    # ---- ONE process, n GPUs: the reference's host model (one frame loop, main.cpp:163-202) ----
+    @staticmethod
+    def comm_init_all(ctxs):
+        """ctxs[i] (one Context per DEVICE) becomes rank i of len(ctxs): rdh_comm_init_all (grouped ncclCommInitRank)."""
+        n = len(ctxs)
+        arr = (C.c_void_p * n)(*[c.h for c in ctxs])
+        rc = lib().rdh_comm_init_all(arr, n)
+        if rc != 0:
+            ctxs[0].check(rc)
+        for i, c in enumerate(ctxs):
+            c.rank, c.world = i, n
+
+    @staticmethod
+    def path_trace_gathered_all(ctxs, direct_frames, indirect_frames, iter, looper, max_depth, flags=RDH_PT_PERSISTENT):
+        """pathTrace on every context of this process (rdh_path_trace_gathered_all): whole-frame images in and out per device."""
+        n = len(ctxs)
+        arr = (C.c_void_p * n)(*[c.h for c in ctxs])
+        px = ctxs[0].width * ctxs[0].height * 3
+        d = (C.c_void_p * n)(*[c._ptr(t, px, "path_trace_gathered_all: direct") for c, t in zip(ctxs, direct_frames)])
+        i = (C.c_void_p * n)(*[c._ptr(t, px, "path_trace_gathered_all: indirect") for c, t in zip(ctxs, indirect_frames)])
+        rc = lib().rdh_path_trace_gathered_all(arr, n, d, i, iter, looper, max_depth, flags)
+        if rc != 0:
+            msgs = [lib().rdh_last_error(c.h) for c in ctxs]
+            raise RadishError(f"libradish_hip error {rc}: " + "; ".join(f"ctx {k}: {m.decode()}" for k, m in enumerate(msgs) if m))
 
     def allgather_tiles(self, packed, frame):
         shard = self.tiles_per_rank() * self.tile * self.tile * 3

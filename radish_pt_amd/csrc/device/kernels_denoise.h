@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_svgf_filter(float *__restrict__ colorOu
     float varianceSum = 0.f, weightSum = 0.f, weight2Sum = 0.f;
 #pragma unroll
     for (int tp = 0; tp < 13; tp++) {
-        __builtin_amdgcn_sched_barrier(0);  // see k_eaw_filter
+        __builtin_amdgcn_sched_barrier(0);  // one tap pair at a time: without the fence the scheduler hoists all 260 LDS reads (214 VGPRs)
         constexpr TapPair kTaps[13] = {RD_PAIR(0), RD_PAIR(2), RD_PAIR(4), RD_PAIR(6), RD_PAIR(8), RD_PAIR(10), RD_PAIR(12),
                                        RD_PAIR(14), RD_PAIR(16), RD_PAIR(18), RD_PAIR(20), RD_PAIR(22), RD_PAIR(24)};
         const TapPair tap = kTaps[tp];

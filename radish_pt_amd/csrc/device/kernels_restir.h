@@ -461,7 +461,10 @@ __global__ __launch_bounds__(256) void k_restir_resolve(DScene s, PixelMap pm, i
     Reservoir reservoir = emptyReservoir();
     if (status >= 0) {
         reservoir = loadReservoir(sp.rawResv, slot);
-        if (sp.occ[slot] != 0) reservoir.weight = 0.f;  // :158-163
+        // :158-163.  A segment whose first float is NaN (a NaN hit position) is an empty slot to the walker: no flag was written for
+        // it, and DevScene::testOcclusion of such a segment fails the root's box test — not occluded
+        const float segX = sp.segs[6 * slot];
+        if (segX == segX && sp.occ[slot] != 0) reservoir.weight = 0.f;
         if (!a.firstFrame && (a.reuseMask & 1)) {       // :165-170
             Reservoir temporal = findTemporalNeighbor(a, idx);
             if (!resvInvalid(temporal)) resvPreClampedMerge(reservoir, temporal, rng.sample(), a.temporalClamp);

@@ -28,7 +28,7 @@ constexpr int kWalkDeferCap = 256;
 template <bool COUNT, bool ANY, bool DEFER = false>
 __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,
                                                         int *__restrict__ occluded, PersistCounters *pc,
-                                                        const int *__restrict__ deferCount = nullptr) {
+                                                        const int *__restrict__ deferCount = nullptr, int slotList = 0) {
     const int lane = int(threadIdx.x) & 63;
     const int end = s.bvhSize;
     const long long chunks = (n + 63) / 64;
@@ -81,9 +81,11 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
                 const int give = (nIdle - taken) < avail ? (nIdle - taken) : avail;
                 if (state == W_IDLE && myRank >= taken && myRank < taken + give) {
                     const long long i = curChunk * 64 + slotNext + (myRank - taken);
-                    // a NaN in the first float marks an empty slot of the list (ReSTIR's per-slot ray lists): no ray, no record,
-                    // nothing counted
-                    if (i < n && rays[6 * i] == rays[6 * i]) {
+                    // slotList (ReSTIR's per-slot ray lists only): a NaN in the first float marks an EMPTY SLOT — no ray, no record,
+                    // nothing counted (the consumer, k_restir_resolve, does not read the record of such a slot either).  The public
+                    // ray-batch entries (rdh_trace_closest / rdh_trace_occluded) pass slotList = 0: a caller's ray with a NaN origin
+                    // is a ray like any other (it fails the root's box test, as in DevScene::intersect) and is counted.
+                    if (i < n && (slotList == 0 || rays[6 * i] == rays[6 * i])) {
                         rayIdx = i;
                         const v3 a = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
                         const v3 b = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);

@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -76,7 +77,8 @@ struct rdh_ctx {
     long long restirPixels = 0;
     // per-slot scratch of the split pass 1 (kernels_restir.h RestirSplit), grown on demand
     void *splitBuf = nullptr;
-    long long splitSlots = 0;
+    long long splitSlots = 0;      // allocation high-water mark
+    long long splitLastSlots = 0;  // slots (= plane stride) of the last split pass 1: what rdh_restir_read_scratch reads back
     unsigned risGrid = 0;
     LightPre *lightPre = nullptr;
     bool restirFirstFrame = true;
@@ -230,9 +232,10 @@ int wfAlloc(rdh_ctx *c, T **out, size_t count) {
     return RDH_OK;
 }
 
-// Workspace for the wavefront pipeline: 152 B of path state + 3 queue slots per path slot, per sub-frame.
+// Workspace for the wavefront pipeline: 152 B of path state + the ray / shadow queue entries per path slot, per sub-frame, plus
+// the two literal-class lists (litq) of kWfLitCap entries.
 int wavefrontEnsure(rdh_ctx *c, const PixelMap &pm) {
-    long long slots = (long long)pm.numBlocks * 64;  // a sub-frame of three holds a third (+ one block); sized for half
+    long long slots = (long long)pm.numBlocks * 64;  // workspace 0: the whole frame; 1 and 2: a third each (+ a block), sized for half
     if (c->wfCapacity >= slots) return RDH_OK;
     for (void *p : c->wfAllocs) hipFree(p);
     c->wfAllocs.clear();
@@ -266,7 +269,8 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     if (maxDepth > kMaxWaveDepth) return fail(c, RDH_ERR_ARGS, "maxDepth %d exceeds %d", maxDepth, kMaxWaveDepth);
     const bool count = (flags & RDH_PT_COUNT) != 0, sort = (flags & RDH_PT_SORT_MATERIAL) != 0;
     // Persistent kernels whose waves take a STATIC first packet: every workgroup must be resident from the start, or the
-    // surplus ones run their static packets after everybody else has finished (k_wf_trace fits 6 waves per SIMD, k_wf_shade 3).
+    // surplus ones run their static packets after everybody else has finished (k_wf_trace: 72 VGPRs, 7 waves per SIMD as 256-thread
+    // workgroups allow; k_wf_shade 3 — tests/test_kernel_resources.py pins the budgets).
     if (c->wfGrid[0] == 0) {
         int cus = 0, per[4] = {0, 0, 1, 0};
         HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -284,64 +288,76 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     // stay one pipeline.
     const int parts = ((flags & RDH_PT_WF_SUBFRAMES) && pm.numBlocks >= 2048) ? kWfParts : 1;
     hipStream_t sts[kWfParts] = {c->stream, c->sideStream, c->wfStream};
+    // persistent grids: what stays resident, shared between the sub-frame pipelines and between the contexts that render side by
+    // side on this GPU (rdh_set_occupancy_share)
+    const unsigned div = (unsigned)parts * (unsigned)c->share;
+    const unsigned traceGrid = std::max(8u, c->wfGrid[count ? 1 : 0] / div), shadeGrid = std::max(8u, c->wfGrid[3] / div);
+    // RDH_PT_PROFILE with sub-frames: the pipelines' launches overlap by design, so what is timed is the FRAME — one event pair
+    // from before the fork to after the join, on the context's stream (one pipeline: a pair around every k_wf_trace launch)
+    const long pf = parts >= 2 ? profBegin(c, flags) : -1;
     if (parts >= 2) {
         HIP_TRY(c, hipEventRecord(c->evWfFork, c->stream));
         for (int h = 1; h < parts; h++) HIP_TRY(c, hipStreamWaitEvent(sts[h], c->evWfFork, 0));
     }
+    // From here on the side streams may hold work: no early return before the join below (an error is carried in `rc`).
+    int rc = RDH_OK;
+    auto keep = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == RDH_OK) rc = fail(c, (int)e, "HIP error (%s:%d): %s: %s", __FILE__, __LINE__, what, hipGetErrorString(e));
+    };
     for (int h = 0; h < parts; h++) {
         hipStream_t st = sts[h];
         WaveWorkspace &w = c->wf[h];
         const unsigned nLocal = (unsigned)(pm.numBlocks - h + parts - 1) / (unsigned)parts;
         const unsigned gridBlk = (((nLocal + 3u) / 4u + 7u) / 8u) * 8u;
-        HIP_TRY(c, hipMemsetAsync(w.ctr, 0, sizeof(WaveCounters), st));
+        keep(hipMemsetAsync(w.ctr, 0, sizeof(WaveCounters), st), "hipMemsetAsync(wavefront counters)");
         hipLaunchKernelGGL(k_wf_raygen, dim3(gridBlk), dim3(256), 0, st, c->ds, c->cam, pm, w, looper, h, parts);
     }
     for (int h = 0; h < parts; h++) {  // what a stage's literal-class list may hold: one entry per lane of the trace grid
-        const unsigned waves = (c->wfGrid[count ? 1 : 0] / (unsigned)parts) * 4u;
+        const unsigned waves = traceGrid * 4u;
         c->wf[h].litCap = (int)(waves * 64u < (unsigned)kWfLitCap ? waves * 64u : (unsigned)kWfLitCap);
         if (flags & RDH_PT_WF_SMALL_LISTS) c->wf[h].litCap = 4;  // tests: what does not fit stays in the ordinary queues
     }
-    for (int k = 0; k <= maxDepth; k++) {
-        for (int h = 0; h < parts; h++) {  // interleaved issue: stage k of both pipelines before stage k + 1 of either
+    for (int k = 0; k <= maxDepth && rc == RDH_OK; k++) {
+        for (int h = 0; h < parts; h++) {  // interleaved issue: stage k of every pipeline before stage k + 1 of any
             hipStream_t st = sts[h];
             WaveWorkspace &w = c->wf[h];
             long pe = (h == 0 && parts == 1) ? profBegin(c, flags) : -1;
-            if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(c->wfGrid[1] / parts), dim3(256), 0, st, c->ds, w, k);
-            else hipLaunchKernelGGL(k_wf_trace<false>, dim3(c->wfGrid[0] / parts), dim3(256), 0, st, c->ds, w, k);
+            if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(traceGrid), dim3(256), 0, st, c->ds, w, k);
+            else hipLaunchKernelGGL(k_wf_trace<false>, dim3(traceGrid), dim3(256), 0, st, c->ds, w, k);
             profEnd(c, pe);
-            hipLaunchKernelGGL(k_wf_shade, dim3(c->wfGrid[3] / parts), dim3(256), 0, st, c->ds, w, k, maxDepth, sort ? 1 : 0);
+            hipLaunchKernelGGL(k_wf_shade, dim3(shadeGrid), dim3(256), 0, st, c->ds, w, k, maxDepth, sort ? 1 : 0);
         }
+        keep(hipGetLastError(), "wavefront stage launch");
     }
-    for (int h = 0; h < parts; h++) {
+    for (int h = 0; h < parts && rc == RDH_OK; h++) {
         hipStream_t st = sts[h];
         const unsigned nLocal = (unsigned)(pm.numBlocks - h + parts - 1) / (unsigned)parts;
         const unsigned gridBlk = (((nLocal + 3u) / 4u + 7u) / 8u) * 8u;
         hipLaunchKernelGGL(k_wf_finish, dim3(gridBlk), dim3(256), 0, st, pm, c->wf[h], iter, d_direct, d_indirect, h, parts);
     }
-    if (parts >= 2) {
-        HIP_TRY(c, hipEventRecord(c->evWfJoin, c->sideStream));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evWfJoin, 0));
-        HIP_TRY(c, hipEventRecord(c->evWfJoin3, c->wfStream));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evWfJoin3, 0));
+    keep(hipGetLastError(), "k_wf_finish");
+    if (parts >= 2) {  // the join is unconditional; if it cannot be expressed with events the side streams are drained
+        hipError_t e1 = hipEventRecord(c->evWfJoin, c->sideStream);
+        hipError_t e2 = hipStreamWaitEvent(c->stream, c->evWfJoin, 0);
+        hipError_t e3 = hipEventRecord(c->evWfJoin3, c->wfStream);
+        hipError_t e4 = hipStreamWaitEvent(c->stream, c->evWfJoin3, 0);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+            hipStreamSynchronize(c->sideStream);
+            hipStreamSynchronize(c->wfStream);
+            keep(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4)), "wavefront join");
+        }
     }
-    return RDH_OK;
+    profEnd(c, pf);
+    return rc;
 }
 
 // k_walk_persistent over a ray list (d_hits xor d_occ): as many single-wave workgroups as stay resident, lane refill.
 // deferCount / deferList (ReSTIR's lists): literal-class rays have been listed by the producer of `d_rays`; they are traced one
 // per workgroup on the side stream beside the walker, which skips them; the stream waits for both before it goes on.
 int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *d_occ, bool count, const int *deferCount = nullptr,
-               const int *deferList = nullptr) {
+               const int *deferList = nullptr, int slotList = 0) {
     const int any = d_occ ? 1 : 0;
-    if (deferCount) {
-        HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evFork, 0));
-        if (any && count) hipLaunchKernelGGL((k_trace_wg_list<true, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
-        else if (any) hipLaunchKernelGGL((k_trace_wg_list<false, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
-        else if (count) hipLaunchKernelGGL((k_trace_wg_list<true, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
-        else hipLaunchKernelGGL((k_trace_wg_list<false, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
-        HIP_TRY(c, hipEventRecord(c->evJoin, c->sideStream));
-    }
+    // everything that can fail comes BEFORE the fork, so that no error path leaves the side stream un-joined
     if (c->walkGrid[any] == 0) {
         int perCU = 0, cus = 0;
         if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, true>), 64, 0));
@@ -350,29 +366,45 @@ int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *
         c->walkGrid[any] = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
     }
     const unsigned long long chunks = (unsigned long long)((n + 63) / 64);
-    const unsigned grid = chunks < c->walkGrid[any] ? (unsigned)chunks : c->walkGrid[any];
+    unsigned resident = c->walkGrid[any] / (unsigned)c->share;  // rdh_set_occupancy_share: contexts side by side on one GPU
+    if (resident < 8u) resident = 8u;
+    const unsigned grid = chunks < resident ? (unsigned)chunks : resident;
     HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
     if (deferCount) {
+        HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
+        hipError_t ew = hipStreamWaitEvent(c->sideStream, c->evFork, 0);
+        if (ew == hipSuccess) {
+            if (any && count) hipLaunchKernelGGL((k_trace_wg_list<true, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+            else if (any) hipLaunchKernelGGL((k_trace_wg_list<false, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+            else if (count) hipLaunchKernelGGL((k_trace_wg_list<true, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+            else hipLaunchKernelGGL((k_trace_wg_list<false, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+        }
         if (any && count)
-            hipLaunchKernelGGL((k_walk_persistent<true, true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount);
+            hipLaunchKernelGGL((k_walk_persistent<true, true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount, slotList);
         else if (any)
-            hipLaunchKernelGGL((k_walk_persistent<false, true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount);
+            hipLaunchKernelGGL((k_walk_persistent<false, true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount, slotList);
         else if (count)
-            hipLaunchKernelGGL((k_walk_persistent<true, false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount);
+            hipLaunchKernelGGL((k_walk_persistent<true, false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount, slotList);
         else
-            hipLaunchKernelGGL((k_walk_persistent<false, false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount);
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evJoin, 0));
+            hipLaunchKernelGGL((k_walk_persistent<false, false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount, slotList);
+        // the join is unconditional: whatever failed above, the stream goes on only after the side stream's work
+        hipError_t e1 = hipEventRecord(c->evJoin, c->sideStream);
+        hipError_t e2 = hipStreamWaitEvent(c->stream, c->evJoin, 0);
+        if (e1 != hipSuccess || e2 != hipSuccess) hipStreamSynchronize(c->sideStream);
+        HIP_TRY(c, ew);
+        HIP_TRY(c, hipGetLastError());
         return RDH_OK;
     }
     const int *none = nullptr;
     if (any && count)
-        hipLaunchKernelGGL((k_walk_persistent<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none);
+        hipLaunchKernelGGL((k_walk_persistent<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none, slotList);
     else if (any)
-        hipLaunchKernelGGL((k_walk_persistent<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none);
+        hipLaunchKernelGGL((k_walk_persistent<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none, slotList);
     else if (count)
-        hipLaunchKernelGGL((k_walk_persistent<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none);
+        hipLaunchKernelGGL((k_walk_persistent<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none, slotList);
     else
-        hipLaunchKernelGGL((k_walk_persistent<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none);
+        hipLaunchKernelGGL((k_walk_persistent<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none, slotList);
+    HIP_TRY(c, hipGetLastError());
     return RDH_OK;
 }
 
@@ -711,7 +743,6 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
             HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_pt_persistent<false>, 64, 0));
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             if (perCU < 1) perCU = 1;
-            if (perCU > 1) perCU -= 0;  // SGPR-heavy kernels: the API can over-report by one (MI355X_MICROARCH.md); VGPR-bound here
             c->persistGrid = (unsigned)(perCU * cus);
         }
         unsigned residentGrid = c->persistGrid / (unsigned)c->share;
@@ -880,6 +911,7 @@ int rdh_restir_free(rdh_ctx *c) {
     if (c->splitBuf) hipFree(c->splitBuf);
     c->splitBuf = nullptr;
     c->splitSlots = 0;
+    c->splitLastSlots = 0;
     c->resvCur = c->resvLast = c->resvTemp = nullptr;
     c->restirState = nullptr;
     c->restirPixels = 0;
@@ -972,6 +1004,7 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
             HIP_TRY(c, hipMalloc(&c->splitBuf, (size_t)slots * kSlotBytes + kDeferBytes));
             c->splitSlots = slots;
         }
+        c->splitLastSlots = slots;
         RestirSplit sp;
         char *base = static_cast<char *>(c->splitBuf);
         sp.st = reinterpret_cast<float4 *>(base);                                  // 48 B, 16-B aligned first
@@ -988,7 +1021,7 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
         const unsigned gridBlk = (nBlocks1 + 3u) / 4u;
         hipLaunchKernelGGL(k_restir_raygen, dim3(gridBlk), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, apronBlocks, sp.rays,
                            sp.deferCount, sp.deferList);
-        if ((rc = launchWalk(c, sp.rays, slots, sp.hits, nullptr, count, defer ? sp.deferCount : nullptr, sp.deferList))) return rc;
+        if ((rc = launchWalk(c, sp.rays, slots, sp.hits, nullptr, count, defer ? sp.deferCount : nullptr, sp.deferList, 1))) return rc;
         const int nLights = c->ds.lightSamplerLength - (c->ds.envSamplerLength != 0 ? 1 : 0);
         const size_t ldsBytes = (size_t)nLights * sizeof(LightPre) + (size_t)c->ds.lightSamplerLength * sizeof(AliasRec);
         const bool staged = nLights > 0 && ldsBytes <= kRisLdsBytes;
@@ -1003,7 +1036,7 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
             hipLaunchKernelGGL(k_restir_ris<true>, dim3(risGrid), dim3(kRisThreads), ldsBytes, c->stream, c->ds, c->cam, pm, looper, a, apronBlocks, sp);
         else
             hipLaunchKernelGGL(k_restir_ris<false>, dim3(risGrid), dim3(kRisThreads), 0, c->stream, c->ds, c->cam, pm, looper, a, apronBlocks, sp);
-        if ((rc = launchWalk(c, sp.segs, slots, nullptr, sp.occ, count, defer ? sp.deferCount + 1 : nullptr, sp.deferList + kRestirDeferCap)))
+        if ((rc = launchWalk(c, sp.segs, slots, nullptr, sp.occ, count, defer ? sp.deferCount + 1 : nullptr, sp.deferList + kRestirDeferCap, 1)))
             return rc;
         hipLaunchKernelGGL(k_restir_resolve, dim3(gridBlk), dim3(256), 0, c->stream, c->ds, pm, iter, a, apronBlocks, sp, d_direct);
     }
@@ -1051,7 +1084,8 @@ int rdh_restir_read(rdh_ctx *c, int which, void *hostOut) {
 long long rdh_restir_read_scratch(rdh_ctx *c, int which, void *hostOut, long long maxBytes) {
     if (!c || which < 0 || which > 2) return RDH_ERR_ARGS;
     if (!c->splitBuf) return fail(c, RDH_ERR_STATE, "rdh_restir_read_scratch: no split pass 1 has run");
-    const size_t slots = (size_t)c->splitSlots;
+    if (c->splitLastSlots <= 0) return fail(c, RDH_ERR_STATE, "rdh_restir_read_scratch: no split pass 1 has run");
+    const size_t slots = (size_t)c->splitLastSlots;  // the planes were laid out with THIS stride (not the allocation's)
     const char *base = static_cast<const char *>(c->splitBuf);
     const char *src = which == 0 ? base + slots * (48 + 16) : (which == 1 ? base + slots * (48 + 16 + 24) : base + slots * 152);
     const size_t bytes = which == 2 ? 16 + 2 * sizeof(int) * kRestirDeferCap : slots * 24;
@@ -1080,33 +1114,55 @@ struct RcclApi {
     int (*CommDestroy)(void *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
-    bool tried = false;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
 };
 RcclApi g_rccl;
 constexpr int kNcclFloat = 7;  // ncclFloat32 (rccl.h ncclDataType_t)
 
-const char *rcclLoad() {
-    if (g_rccl.AllGather) return nullptr;
-    if (g_rccl.tried) return "RCCL could not be loaded";
-    g_rccl.tried = true;
+// Resolved once per process (std::call_once: a host that drives several GPUs from one thread each may get here concurrently).
+// Order: RADISH_RCCL_LIB; the nccl* symbols the process already holds in its global scope (a statically linked RCCL, or one
+// loaded RTLD_GLOBAL) — resolved with dlsym(RTLD_DEFAULT, ...), no second copy is loaded; a librccl the process has loaded
+// privately (PyTorch's: RTLD_NOLOAD finds it); finally ROCm's own.
+std::once_flag g_rcclOnce;
+const char *g_rcclWhy = nullptr;
+void rcclLoadOnce() {
     void *h = nullptr;
-    // 1. a copy this process already holds (PyTorch's: same HIP runtime as the streams we are given); 2. ROCm's
+    bool global = false;
     const char *env = getenv("RADISH_RCCL_LIB");
-    if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-    if (!h && dlsym(RTLD_DEFAULT, "ncclAllGather")) h = RTLD_DEFAULT;
+    if (env && *env) {
+        h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            g_rcclWhy = "RADISH_RCCL_LIB could not be loaded";
+            return;
+        }
+    }
+    if (!h && dlsym(RTLD_DEFAULT, "ncclAllGather") && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) global = true;
     const char *names[] = {"librccl.so.1", "librccl.so"};
-    for (int k = 0; !h && k < 2; k++) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-    for (int k = 0; !h && k < 2; k++) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
-    if (!h) return "librccl.so not found (set RADISH_RCCL_LIB)";
+    for (int k = 0; !h && !global && k < 2; k++) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    for (int k = 0; !h && !global && k < 2; k++) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+    if (!h && !global) {
+        g_rcclWhy = "librccl.so not found (set RADISH_RCCL_LIB)";
+        return;
+    }
+    void *scope = global ? RTLD_DEFAULT : h;  // RTLD_DEFAULT is a null handle on glibc: `global` carries the decision
     g_rccl.handle = h;
-    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
-    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
-    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    auto ag = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(h, "ncclAllGather"));
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !ag) return "librccl.so lacks the nccl* entry points";
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(scope, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(scope, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(scope, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(scope, "ncclGetErrorString"));
+    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(dlsym(scope, "ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(scope, "ncclGroupEnd"));
+    auto ag = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(scope, "ncclAllGather"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !ag) {
+        g_rcclWhy = "librccl.so lacks the nccl* entry points";
+        return;
+    }
     g_rccl.AllGather = ag;
-    return nullptr;
+}
+const char *rcclLoad() {
+    std::call_once(g_rcclOnce, rcclLoadOnce);
+    return g_rccl.AllGather ? nullptr : (g_rcclWhy ? g_rcclWhy : "RCCL could not be loaded");
 }
 
 int rcclFail(rdh_ctx *c, int r, const char *what) {
@@ -1127,14 +1183,22 @@ int commEnsure(rdh_ctx *c, float **buf, size_t *have, size_t floats) {
 }
 
 // send: this rank's packed tiles, `channels` floats per pixel -> c->commRecv: the packed tiles of every rank, rank-major
-int allGatherPacked(rdh_ctx *c, const float *d_send, int channels, const PixelMap &pm) {
+int gatherEnsure(rdh_ctx *c, int channels, const PixelMap &pm) {  // may allocate (and then synchronises): never inside a group
     if (!c->comm) return fail(c, RDH_ERR_STATE, "no communicator: call rdh_comm_init first");
     const size_t shard = (size_t)pm.tilesPerRank * pm.tile * pm.tile * channels;
-    int rc = commEnsure(c, &c->commRecv, &c->commRecvFloats, shard * (size_t)pm.world);
-    if (rc) return rc;
+    return commEnsure(c, &c->commRecv, &c->commRecvFloats, shard * (size_t)pm.world);
+}
+int gatherEnqueue(rdh_ctx *c, const float *d_send, int channels, const PixelMap &pm) {
+    const size_t shard = (size_t)pm.tilesPerRank * pm.tile * pm.tile * channels;
     int r = g_rccl.AllGather(d_send, c->commRecv, shard, kNcclFloat, c->comm, c->stream);
     if (r != 0) return rcclFail(c, r, "ncclAllGather");
     return RDH_OK;
+}
+int allGatherPacked(rdh_ctx *c, const float *d_send, int channels, const PixelMap &pm) {
+    int rc = gatherEnsure(c, channels, pm);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return gatherEnqueue(c, d_send, channels, pm);
 }
 }  // namespace
 }  // extern "C++"
@@ -1158,6 +1222,45 @@ int rdh_comm_init(rdh_ctx *c, const void *id128, int rank, int world) {
     if (r != 0) return rcclFail(c, r, "ncclCommInitRank");
     c->comm = comm;
     return rdh_set_partition(c, rank, world, c->tile);
+}
+
+// One PROCESS, n devices (the reference's host is one process with one frame loop, main.cpp:163-202): the
+// communicators of all n contexts are created inside one RCCL group, so a single host thread can do it (ncclCommInitRank by
+// itself blocks until every rank has arrived).  ctxs[i] becomes rank i of n; its tile partition is set accordingly.
+int rdh_comm_init_all(rdh_ctx **ctxs, int n) {
+    if (!ctxs || n < 1) return RDH_ERR_ARGS;
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i]) return RDH_ERR_ARGS;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+            if (ctxs[i] == ctxs[j] || ctxs[i]->device == ctxs[j]->device)
+                return fail(ctxs[0], RDH_ERR_ARGS, "rdh_comm_init_all: contexts %d and %d share a device (RCCL wants one rank per GPU)", j, i);
+    rdh_ctx *c0 = ctxs[0];
+    const char *why = rcclLoad();
+    if (why) return fail(c0, RDH_ERR_COMM, "%s", why);
+    Id128 id;
+    int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) return rcclFail(c0, r, "ncclGetUniqueId");
+    for (int i = 0; i < n; i++) rdh_comm_destroy(ctxs[i]);
+    std::vector<void *> comms((size_t)n, nullptr);
+    if ((r = g_rccl.GroupStart()) != 0) return rcclFail(c0, r, "ncclGroupStart");
+    int rInit = 0;
+    for (int i = 0; i < n && rInit == 0; i++) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) rInit = -1;
+        else rInit = g_rccl.CommInitRank(&comms[(size_t)i], n, id, i);
+    }
+    r = g_rccl.GroupEnd();  // the group is always closed
+    if (rInit != 0 || r != 0) {
+        for (int i = 0; i < n; i++)
+            if (comms[(size_t)i]) g_rccl.CommDestroy(comms[(size_t)i]);
+        return rInit == -1 ? fail(c0, RDH_ERR_NO_DEVICE, "rdh_comm_init_all: hipSetDevice failed") : rcclFail(c0, rInit != 0 ? rInit : r, "ncclCommInitRank (grouped)");
+    }
+    for (int i = 0; i < n; i++) {
+        ctxs[i]->comm = comms[(size_t)i];
+        int rc = rdh_set_partition(ctxs[i], i, n, ctxs[i]->tile);
+        if (rc) return rc;
+    }
+    return RDH_OK;
 }
 
 int rdh_comm_destroy(rdh_ctx *c) {
@@ -1204,8 +1307,10 @@ int packFrame(rdh_ctx *c, const float *d_frame, int k, int channels, const Pixel
 }  // namespace
 }
 
-int rdh_path_trace_gathered(rdh_ctx *c, float *d_directFrame, float *d_indirectFrame, int iter, int looper, int maxDepth,
-                            uint32_t flags) {
+extern "C++" {
+namespace {
+// rdh_path_trace_gathered, first half: the caller's frames -> this rank's packed tiles (the running mean reads them), render.
+int gatheredRender(rdh_ctx *c, const float *d_directFrame, const float *d_indirectFrame, int iter, int looper, int maxDepth, uint32_t flags) {
     int rc = requireReady(c);
     if (rc) return rc;
     if (!d_directFrame || !d_indirectFrame) return fail(c, RDH_ERR_ARGS, "rdh_path_trace_gathered: null image");
@@ -1217,10 +1322,55 @@ int rdh_path_trace_gathered(rdh_ctx *c, float *d_directFrame, float *d_indirectF
         rc = rdh_path_trace(c, c->commSend[0], c->commSend[1], iter, looper, maxDepth, flags);
     c->forcePacked = false;
     if (rc) return rc;
-    if ((rc = allGatherPacked(c, c->commSend[0], 3, pm))) return rc;
+    return gatherEnsure(c, 3, pm);
+}
+PixelMap packedMap(rdh_ctx *c) {
+    PixelMap pm = makePixelMap(c);
+    pm.packed = 1;
+    return pm;
+}
+}  // namespace
+}
+
+int rdh_path_trace_gathered(rdh_ctx *c, float *d_directFrame, float *d_indirectFrame, int iter, int looper, int maxDepth,
+                            uint32_t flags) {
+    int rc = gatheredRender(c, d_directFrame, d_indirectFrame, iter, looper, maxDepth, flags);
+    if (rc) return rc;
+    const PixelMap pm = packedMap(c);
+    if ((rc = gatherEnqueue(c, c->commSend[0], 3, pm))) return rc;
     if ((rc = rdh_untile(c, c->commRecv, d_directFrame))) return rc;
-    if ((rc = allGatherPacked(c, c->commSend[1], 3, pm))) return rc;
+    if ((rc = gatherEnqueue(c, c->commSend[1], 3, pm))) return rc;
     return rdh_untile(c, c->commRecv, d_indirectFrame);
+}
+
+// The same for n contexts of ONE process (rdh_comm_init_all): every context's render is enqueued first (asynchronous, one stream
+// per device: the GPUs render side by side), then one RCCL group per image holds the n all-gathers — issued one after the other
+// outside a group, the first would wait for peers whose call the same thread has not made yet.
+int rdh_path_trace_gathered_all(rdh_ctx **ctxs, int n, float *const *d_directFrames, float *const *d_indirectFrames, int iter, int looper,
+                                int maxDepth, uint32_t flags) {
+    if (!ctxs || n < 1 || !d_directFrames || !d_indirectFrames) return RDH_ERR_ARGS;
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i]) return RDH_ERR_ARGS;
+    for (int i = 0; i < n; i++) {
+        if (ctxs[i]->world != n || ctxs[i]->rank != i)
+            return fail(ctxs[i], RDH_ERR_STATE, "rdh_path_trace_gathered_all: context %d is rank %d of %d (rdh_comm_init_all first)", i, ctxs[i]->rank, ctxs[i]->world);
+        int rc = gatheredRender(ctxs[i], d_directFrames[i], d_indirectFrames[i], iter, looper, maxDepth, flags);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < 2; k++) {
+        int r = g_rccl.GroupStart(), rc = RDH_OK;
+        if (r != 0) return rcclFail(ctxs[0], r, "ncclGroupStart");
+        for (int i = 0; i < n && rc == RDH_OK; i++) {
+            if (hipSetDevice(ctxs[i]->device) != hipSuccess) rc = fail(ctxs[i], RDH_ERR_NO_DEVICE, "hipSetDevice(%d)", ctxs[i]->device);
+            else rc = gatherEnqueue(ctxs[i], ctxs[i]->commSend[k], 3, packedMap(ctxs[i]));
+        }
+        r = g_rccl.GroupEnd();
+        if (rc) return rc;
+        if (r != 0) return rcclFail(ctxs[0], r, "ncclGroupEnd");
+        for (int i = 0; i < n; i++)
+            if ((rc = rdh_untile(ctxs[i], ctxs[i]->commRecv, k == 0 ? d_directFrames[i] : d_indirectFrames[i]))) return rc;
+    }
+    return RDH_OK;
 }
 
 int rdh_restir_exchange(rdh_ctx *c) {

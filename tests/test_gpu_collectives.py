@@ -73,6 +73,79 @@ def test_rccl_one_rank_path_trace_gathered(cornell_small):
         ref_ctx.close()
 
 
+def test_one_process_group_init_and_gathered_all(cornell_small):
+    """The ONE-process host model (the reference is one process with one frame loop, main.cpp:163-202):
+    rdh_comm_init_all creates the communicators of n contexts inside one RCCL group and rdh_path_trace_gathered_all renders and
+    gathers for all of them from one thread.  One GPU here, so n = 1 (two contexts on one device must be refused — RCCL wants a
+    device per rank); the n = 2 form runs in test_one_process_two_gpus where two devices exist."""
+    from radish_pt_amd import api, scenes
+
+    torch = _torch()
+    W, H, depth = 200, 120, 4
+    cam = scenes.cornell_camera(W, H)
+    ref_ctx, ctx, ctx_b = api.Context(0), api.Context(0), api.Context(0)
+    try:
+        for c in (ref_ctx, ctx, ctx_b):
+            c.upload_scene(cornell_small)
+            c.set_camera(cam)
+        ctx.set_partition(0, 1, 32)
+        with pytest.raises(api.RadishError):
+            api.Context.comm_init_all([ctx, ctx_b])  # same device twice
+        rd, ri = torch.zeros(W * H, 3, device="cuda"), torch.zeros(W * H, 3, device="cuda")
+        gd, gi = torch.zeros(W * H, 3, device="cuda"), torch.zeros(W * H, 3, device="cuda")
+        with pytest.raises(api.RadishError):
+            api.Context.path_trace_gathered_all([ctx], [gd], [gi], 0, 0, depth)  # no communicator yet
+        api.Context.comm_init_all([ctx])
+        assert (ctx.rank, ctx.world) == (0, 1)
+        for it, flags in enumerate((api.RDH_PT_PERSISTENT, api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL)):
+            ref_ctx.path_trace(rd, ri, it, 40 + it, depth, api.RDH_PT_PERSISTENT)
+            api.Context.path_trace_gathered_all([ctx], [gd], [gi], it, 40 + it, depth, flags)
+        ctx.synchronize()
+        ref_ctx.synchronize()
+        assert_bit_equal(gd.cpu().numpy(), rd.cpu().numpy(), "gathered_all direct")
+        assert_bit_equal(gi.cpu().numpy(), ri.cpu().numpy(), "gathered_all indirect")
+        assert float(ri.max()) > 0
+    finally:
+        for c in (ctx, ctx_b, ref_ctx):
+            c.close()
+
+
+@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two GPUs")
+def test_one_process_two_gpus(cornell_small):
+    """n = 2 contexts of ONE process on two devices: grouped communicator creation, grouped all-gathers; both devices end up with
+    the whole frame, equal to the single-GPU render."""
+    from radish_pt_amd import api, scenes
+
+    torch = _torch()
+    W, H, depth = 200, 120, 4
+    cam = scenes.cornell_camera(W, H)
+    ref_ctx = api.Context(0)
+    ctxs = [api.Context(0, use_torch_stream=False), api.Context(1, use_torch_stream=False)]
+    try:
+        for c in [ref_ctx] + ctxs:
+            c.upload_scene(cornell_small)
+            c.set_camera(cam)
+        for c in ctxs:
+            c.set_partition(0, 1, 32)
+        api.Context.comm_init_all(ctxs)
+        rd, ri = torch.zeros(W * H, 3, device="cuda:0"), torch.zeros(W * H, 3, device="cuda:0")
+        gd = [torch.zeros(W * H, 3, device=f"cuda:{k}") for k in range(2)]
+        gi = [torch.zeros(W * H, 3, device=f"cuda:{k}") for k in range(2)]
+        torch.cuda.synchronize(0)
+        torch.cuda.synchronize(1)
+        for it in range(2):
+            ref_ctx.path_trace(rd, ri, it, 50 + it, depth, api.RDH_PT_PERSISTENT)
+            api.Context.path_trace_gathered_all(ctxs, gd, gi, it, 50 + it, depth, api.RDH_PT_PERSISTENT)
+        for c in [ref_ctx] + ctxs:
+            c.synchronize()
+        for k in range(2):
+            assert_bit_equal(gd[k].cpu().numpy(), rd.cpu().numpy(), f"device {k} direct")
+            assert_bit_equal(gi[k].cpu().numpy(), ri.cpu().numpy(), f"device {k} indirect")
+    finally:
+        for c in ctxs + [ref_ctx]:
+            c.close()
+
+
 def test_rccl_one_rank_restir_gathered():
     """ReSTIRDirect for N GPUs at N = 1: partitioned G-buffer + rdh_gbuffer_exchange, rdh_restir_direct_gathered (image
     all-gather + reservoir exchange inside), three frames with a moving camera: G-buffer planes, images and reservoirs equal

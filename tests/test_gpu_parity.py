@@ -74,6 +74,47 @@ def test_trace_closest_bit_exact(cornell_gpu, cornell_small, kernel):
     assert ct["closestHits"] == st["closestHits"]
 
 
+def test_nan_origin_ray_gets_a_record_in_every_walker(cornell_gpu, cornell_small):
+    """A caller's ray whose origin.x is NaN is a ray like any other for the public ray-batch entries: DevScene::intersect /
+    testOcclusion fail the root's box test and return a miss / not-occluded record, and the ray is counted.  The lane-refill
+    walker (RDH_PT_PERSISTENT) uses a NaN first float as the EMPTY-SLOT mark of ReSTIR's per-slot lists — that reading must stay
+    inside ReSTIR (round-2 advisor finding: such a ray left hits[i] / occluded[i] unwritten and uncounted)."""
+    from radish_pt_amd import api, layouts as L
+
+    torch = _torch()
+    rays = random_rays(512, seed=23)
+    seg = random_segments(512, seed=29)
+    for k in (0, 63, 64, 200, 511):
+        rays[k, 0] = np.nan
+        seg[k, 0] = np.nan
+    rays[17, 4] = np.nan  # a NaN direction component as well
+    o = _oracle(cornell_small)
+    ref_h, st_h = o.trace_closest(rays), None
+    st_h = o.stats()
+    o.reset_stats()
+    ref_o = o.trace_occluded(seg)
+    st_o = o.stats()
+    for flags in (0, api.RDH_PT_PERSISTENT):
+        d_hits = torch.full((len(rays), 4), 0x7fffffff, dtype=torch.int32, device="cuda")  # poison: an unwritten record shows
+        cornell_gpu.counters_reset()
+        cornell_gpu.trace_closest(_dev(rays), d_hits, api.RDH_PT_COUNT | flags)
+        got = d_hits.cpu().numpy().view(L.HIT_DTYPE).reshape(-1)
+        assert np.array_equal(got["primId"], ref_h["primId"]), flags
+        for f in ("u", "v", "t"):
+            assert_bit_equal(got[f], ref_h[f], f"hit.{f} flags={flags}")
+        assert got["primId"][[0, 63, 64, 200, 511]].tolist() == [-1] * 5
+        ct = cornell_gpu.counters()
+        assert ct["closestRays"] == st_h["closestRays"] == len(rays)
+        assert ct["nodeVisits"] == st_h["nodeVisits"] and ct["triTests"] == st_h["triTests"]
+        d_occ = torch.full((len(seg),), -7, dtype=torch.int32, device="cuda")
+        cornell_gpu.counters_reset()
+        cornell_gpu.trace_occluded(_dev(seg), d_occ, api.RDH_PT_COUNT | flags)
+        assert np.array_equal(d_occ.cpu().numpy(), ref_o), flags
+        ct = cornell_gpu.counters()
+        assert ct["anyRays"] == st_o["anyRays"] == len(seg)
+        assert ct["nodeVisits"] == st_o["nodeVisits"] and ct["triTests"] == st_o["triTests"]
+
+
 @pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent"])
 def test_trace_occluded_exact(cornell_gpu, cornell_small, kernel):
     from radish_pt_amd import api
