@@ -108,6 +108,9 @@ typedef struct rdh_counters {
                                   (k_restir_pass1), instead of raygen / walk / RIS / walk / resolve (default; same results) */
 #define RDH_PT_WF_SMALL_LISTS 4096u /* wavefront only, for tests: the per-stage lists of literal-class rays hold 4 entries, so that the
                                   overflow path (such rays stay in the ordinary queues) runs */
+#define RDH_PT_LOOKAHEAD 8192u  /* persistent only: force the LATENCY form of the box loop (several records per round trip; chosen
+                                  automatically for launches with few pixels per resident lane — a rank's share on 4-8 GPUs) */
+#define RDH_PT_NO_LOOKAHEAD 16384u /* persistent only: force the bulk form (one record per step) */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_pt_persistent, k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read.  With

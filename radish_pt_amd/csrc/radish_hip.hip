@@ -27,6 +27,14 @@
 
 using namespace rd;
 
+#ifndef RD_PERSIST_LOOK
+#define RD_PERSIST_LOOK 4
+#endif
+#ifndef RD_PERSIST_LOOK_BLOCKS_PER_WAVE
+#define RD_PERSIST_LOOK_BLOCKS_PER_WAVE 3
+#endif
+constexpr int kPersistLook = RD_PERSIST_LOOK;  // records per round trip of k_pt_persistent's latency form
+constexpr int kPersistLookBlocksPerWave = RD_PERSIST_LOOK_BLOCKS_PER_WAVE;  // ... used when the launch has at most this many 8x8 blocks per resident wave
 constexpr int kWfParts = 3;  // sub-frame pipelines of the wavefront path (RDH_PT_WF_SUBFRAMES)
 
 struct rdh_ctx {
@@ -45,7 +53,8 @@ struct rdh_ctx {
     std::vector<void *> sceneAllocs;
     Counters *dCounters = nullptr;
     PersistCounters *dPersist = nullptr;
-    unsigned persistGrid = 0;
+    unsigned persistGrid = 0;      // resident waves of k_pt_persistent, bulk form
+    unsigned persistGridLook = 0;  // ... of its latency form (kernels_persist.h, LOOK > 1)
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
     unsigned wfGrid[4] = {0, 0, 0, 0};  // resident workgroups of k_wf_trace<false> / <true>, (unused), k_wf_shade
@@ -739,13 +748,22 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         // The grid must be fully resident: a workgroup that starts late would start its static first blocks late.
         unsigned groups = (((unsigned)(pm.numBlocks + 3) / 4 + 7u) / 8u) * 8u * 4u;  // one wave per workgroup
         if (c->persistGrid == 0) {
-            int perCU = 0, cus = 0;
-            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_pt_persistent<false>, 64, 0));
+            int perCU = 0, perCULook = 0, cus = 0;
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_pt_persistent<false, 1>), 64, 0));
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCULook, (k_pt_persistent<false, kPersistLook>), 64, 0));
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             if (perCU < 1) perCU = 1;
+            if (perCULook < 1) perCULook = 1;
             c->persistGrid = (unsigned)(perCU * cus);
+            c->persistGridLook = (unsigned)(perCULook * cus);
         }
-        unsigned residentGrid = c->persistGrid / (unsigned)c->share;
+        // Which form of the box loop (kernels_persist.h): the LATENCY form (LOOK records per round trip) when the launch holds few
+        // pixels per resident lane — a rank's share of the frame on 4-8 GPUs — so that it lasts one path latency whatever the
+        // throughput; the bulk form otherwise.  RDH_PT_LOOKAHEAD / RDH_PT_NO_LOOKAHEAD force either (tests, measurements).
+        bool look = (unsigned long long)pm.numBlocks <= (unsigned long long)kPersistLookBlocksPerWave * (c->persistGridLook / (unsigned)c->share);
+        if (flags & RDH_PT_LOOKAHEAD) look = true;
+        if (flags & RDH_PT_NO_LOOKAHEAD) look = false;
+        unsigned residentGrid = (look ? c->persistGridLook : c->persistGrid) / (unsigned)c->share;
         if (residentGrid < 8u) residentGrid = 8u;
         unsigned grid = groups < residentGrid ? groups : residentGrid;
         // longest-paths-first schedule from the previous launch's per-block costs (same partition and resolution only)
@@ -786,11 +804,17 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
         const int *order = useOrder ? c->blockOrder[cb] : nullptr;
         long pp = profBegin(c, flags);
-        if (count)
-            hipLaunchKernelGGL(k_pt_persistent<true>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+        if (count && look)
+            hipLaunchKernelGGL((k_pt_persistent<true, kPersistLook>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
+        else if (count)
+            hipLaunchKernelGGL((k_pt_persistent<true, 1>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
+        else if (look)
+            hipLaunchKernelGGL((k_pt_persistent<false, kPersistLook>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
                                maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
         else
-            hipLaunchKernelGGL(k_pt_persistent<false>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+            hipLaunchKernelGGL((k_pt_persistent<false, 1>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
                                maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
         profEnd(c, pp);
         // this launch's costs -> running means -> block order for launch n + 2, on the side stream

@@ -4,11 +4,15 @@ import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from radish_pt_amd import api, scenes
 scene = sys.argv[1] if len(sys.argv) > 1 else "cornell"
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # this rank's share of an N-GPU job (rank 0), no collective
+rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 sd = scenes.cornell() if scene == "cornell" else scenes.teapots()
 W, H = 1920, 1080
 cam = scenes.cornell_camera(W, H) if scene == "cornell" else scenes.teapots_camera(W, H)
-ctx = api.Context(0); ctx.upload_scene(sd); ctx.set_camera(cam)
-d = torch.zeros(W*H, 3, device='cuda'); i = torch.zeros(W*H, 3, device='cuda')
+ctx = api.Context(0); ctx.upload_scene(sd); ctx.set_camera(cam); ctx.set_partition(rank, world, 64)
+npx = W * H if world == 1 else ctx.tiles_per_rank() * 64 * 64
+d = torch.zeros(npx, 3, device='cuda'); i = torch.zeros(npx, 3, device='cuda')
+print(f"scene {scene}, rank {rank} of {world}: {npx} pixels")
 for it in range(3):
     ctx.path_trace(d, i, 0, it, 8, api.RDH_PT_PERSISTENT)
 ctx.synchronize()
