@@ -347,13 +347,19 @@ def main():
     tile = args.tile or 64
     mode = args.mode
     mode_choice = None
-    if mode == "auto":
+    if mode == "auto" and world == 1:
         mode = "wavefront_sort2"
-        mode_choice = ("auto -> wavefront_sort2: BASELINE config 3's named structure (material-sorted wavefront + stream compaction; three "
+        mode_choice = ("auto, N = 1 -> wavefront_sort2: BASELINE config 3's named structure (material-sorted wavefront + stream compaction; three "
                        "sub-frame pipelines); on this scene it is also the fastest structure but for its own unsorted form (DESIGN §6)")
+    elif mode == "auto":
+        mode = "persistent"
+        mode_choice = ("auto, N > 1 -> persistent: a rank's share of the frame is small, and the wavefront pipeline ends nine stages per frame on "
+                       "their longest ray where the persistent kernel ends once on its longest path — one rank's share of this frame measured "
+                       "on one GPU (scripts/partition_times.py, profiles/r03_a_partition_times_teapots.txt): 5.51 / 3.47 / 2.58 ms persistent "
+                       "against 5.89 / 4.52 / 4.05 ms wavefront_sort2 at 2 / 4 / 8 ranks (N = 1: 9.68 against 9.20).  Same pixels, bit for bit")
     sd = make_scene(scene_name)
     cam = make_camera(scene_name, W, H)
-    flags = mode_flags(api, mode)
+    flags = flags_main = mode_flags(api, mode)
     subframes = bool(flags & api.RDH_PT_WF_SUBFRAMES)
     K, Wm = args.steps, args.warmup
 
@@ -429,8 +435,9 @@ def main():
                     self.ctx.untile(self.gath_d, self.frame_d)
                     self.ctx.untile(self.gath_i, self.frame_i)
 
-    def measure(F, lib_comm, slots=None, use_lib=True):
+    def measure(F, lib_comm, slots=None, use_lib=True, flags=None):
         """Warm up, count, then time exactly K frames with F frames in flight.  Returns a dict of this rank's figures."""
+        flags = flags_main if flags is None else flags
         if slots is None:
             slots = [Slot(F, lib_comm) for _ in range(F)]
         comm_stream = torch.cuda.Stream(device=dev) if (F > 1 and world > 1) else None
@@ -484,12 +491,14 @@ def main():
                  "unit": "Mrays/s", "ms_per_step": round(mc["elapsed"] / K * 1e3, 4)}
     pipelined = None
     if not args.no_pipelined and F == 1:
-        Fp = min(8, max(3, world))
-        mp_ = measure(Fp, False)
-        pipelined = {"frames_in_flight": Fp, "value": round(mp_["rays_total"] / mp_["elapsed"] / 1e6, 3), "unit": "Mrays/s",
+        Fp = 3  # the same at every N, so that this figure has a like-for-like scaling curve of its own (3 measured best on one GPU)
+        mp_ = measure(Fp, False, flags=api.RDH_PT_PERSISTENT)
+        pipelined = {"frames_in_flight": Fp, "mode": "persistent", "value": round(mp_["rays_total"] / mp_["elapsed"] / 1e6, 3), "unit": "Mrays/s",
                      "ms_per_step": round(mp_["elapsed"] / K * 1e3, 4),
-                     "note": "throughput with several frames in flight per GPU (each on its own stream, persistent grids divided "
-                             "by F" + ("; torch.distributed collectives on one shared stream" if world > 1 else "") + "); not a frame latency, not the headline"}
+                     "note": "throughput with 3 frames in flight per GPU at every N (each on its own stream, one persistent launch per frame, "
+                             "grids divided by 3" + ("; torch.distributed collectives on one shared stream" if world > 1 else "") + "): the tail of one "
+                             "frame — a launch lasts at least one path latency, which does not shrink with a rank's share (DESIGN §8) — is filled by "
+                             "the next; not a frame latency, not the headline"}
         for sl in mp_["slots"]:
             sl.ctx.close()
     slots = m["slots"]
@@ -806,7 +815,8 @@ def run_restir(args, torch, np, api, dist, dev, world, rank, backend, barrier, a
             ctx.restir_exchange_pack(packed9)
             ctx.synchronize()
             ctx.restir_exchange_unpack(gather(packed9))
-        ctx.synchronize()
+        if not lib_comm:  # the reference blocks after every call (cudaUtil.h:18); with the library's exchanges the frames are stream-
+            ctx.synchronize()  # ordered instead, so that the reservoir gather runs beside the next frame's G-buffer pass and pass 1
         gb.update(cam)
 
     for f in range(Wm):

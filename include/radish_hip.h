@@ -108,9 +108,6 @@ typedef struct rdh_counters {
                                   (k_restir_pass1), instead of raygen / walk / RIS / walk / resolve (default; same results) */
 #define RDH_PT_WF_SMALL_LISTS 4096u /* wavefront only, for tests: the per-stage lists of literal-class rays hold 4 entries, so that the
                                   overflow path (such rays stay in the ordinary queues) runs */
-#define RDH_PT_LOOKAHEAD 8192u  /* persistent only: force the LATENCY form of the box loop (several records per round trip; chosen
-                                  automatically for launches with few pixels per resident lane — a rank's share on 4-8 GPUs) */
-#define RDH_PT_NO_LOOKAHEAD 16384u /* persistent only: force the bulk form (one record per step) */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_pt_persistent, k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read.  With
@@ -211,7 +208,16 @@ int rdh_gbuffer_exchange_unpack(rdh_ctx *ctx, const rdh_gbuffer *gb, const float
  *                                until every rank has called it and therefore needs a thread or process per rank)
  *   rdh_path_trace_gathered_all  rdh_path_trace_gathered for all n contexts from one thread: n renders enqueued on n streams,
  *                                then per image ONE RCCL group with the n all-gathers, then n un-tile kernels.
- *                                d_directFrames[i] / d_indirectFrames[i]: whole-frame images on ctxs[i]'s device.              */
+ *                                d_directFrames[i] / d_indirectFrames[i]: whole-frame images on ctxs[i]'s device.
+ *   rdh_gbuffer_exchange_all / rdh_restir_direct_gathered_all   the same for the ReSTIR frame: gbs[i] is context i's G-buffer
+ *                                (planes on its device); one RCCL group per collective.
+ * ReSTIR's exchanges OVERLAP rendering (default; rdh_comm_set_overlap(ctx, 0) puts everything back on the render stream): every
+ * collective of rdh_gbuffer_exchange / rdh_restir_direct_gathered / rdh_restir_exchange is issued on a communication stream of
+ * the context, in one order.  The G-buffer gather runs beside pass 1's ray generation, walks and RIS — rdh_restir_direct waits
+ * for it where it first reads the planes (resolve step) — and the reservoir gather runs beside the NEXT frame's G-buffer pass and
+ * pass 1.  The gathered IMAGE is complete in render-stream order when rdh_restir_direct_gathered returns.  Anything else that
+ * reads G-buffer planes after rdh_gbuffer_exchange (the denoisers and rdh_copy_image_to_pbo do it themselves) calls
+ * rdh_comm_join first: the render stream then waits for the exchanges in flight.  rdh_synchronize waits for both streams.        */
 int rdh_comm_unique_id(void *id128);
 int rdh_comm_init(rdh_ctx *ctx, const void *id128, int rank, int world);
 int rdh_comm_init_all(rdh_ctx **ctxs, int n);
@@ -225,6 +231,11 @@ int rdh_restir_exchange(rdh_ctx *ctx);
 int rdh_restir_direct_gathered(rdh_ctx *ctx, float *d_directFrame, int iter, int looper, const rdh_gbuffer *gb,
                                const rdh_restir_params *params, uint32_t flags);
 int rdh_gbuffer_exchange(rdh_ctx *ctx, const rdh_gbuffer *gb);
+int rdh_gbuffer_exchange_all(rdh_ctx **ctxs, int n, const rdh_gbuffer *gbs);
+int rdh_restir_direct_gathered_all(rdh_ctx **ctxs, int n, float *const *d_directFrames, int iter, int looper, const rdh_gbuffer *gbs,
+                                   const rdh_restir_params *params, uint32_t flags);
+int rdh_comm_set_overlap(rdh_ctx *ctx, int enable);
+int rdh_comm_join(rdh_ctx *ctx);
 
 /* Display path (the step after the hot path): replaces copyImageToPBO's four overloads → sendImageToPBO
  * (/root/reference/src/pathtrace.cu:32-147; declared src/pathtrace.h:25-29).  d_pbo: uchar4[width*height] (alpha 0).

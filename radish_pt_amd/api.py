@@ -37,8 +37,6 @@ RDH_PT_PARTITION_GBUFFER = 512
 RDH_PT_RESTIR_FUSED = 1024
 RDH_PT_WF_SUBFRAMES = 2048
 RDH_PT_WF_SMALL_LISTS = 4096
-RDH_PT_LOOKAHEAD = 8192
-RDH_PT_NO_LOOKAHEAD = 16384
 SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12
 
 # Every symbol include/radish_hip.h declares (tests check that the library exports all of them).
@@ -51,7 +49,8 @@ EXPORTS = [
     "rdh_last_kernel_ms", "rdh_profile_reset", "rdh_profile_read", "rdh_debug_persist_stamps", "rdh_debug_persist_phases",
     "rdh_gbuffer_exchange_pack", "rdh_gbuffer_exchange_unpack", "rdh_comm_unique_id", "rdh_comm_init", "rdh_comm_destroy",
     "rdh_dump_rays", "rdh_set_occupancy_share", "rdh_allgather_tiles", "rdh_path_trace_gathered", "rdh_restir_exchange", "rdh_restir_direct_gathered", "rdh_gbuffer_exchange",
-    "rdh_comm_init_all", "rdh_path_trace_gathered_all",
+    "rdh_comm_init_all", "rdh_path_trace_gathered_all", "rdh_gbuffer_exchange_all", "rdh_restir_direct_gathered_all",
+    "rdh_comm_set_overlap", "rdh_comm_join",
 ]
 
 
@@ -154,6 +153,10 @@ def lib():
             "rdh_comm_destroy": ([vp], i32),
             "rdh_comm_init_all": ([C.POINTER(vp), i32], i32),
             "rdh_path_trace_gathered_all": ([C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp), i32, i32, i32, u32], i32),
+            "rdh_gbuffer_exchange_all": ([C.POINTER(vp), i32, C.POINTER(GBufferC)], i32),
+            "rdh_restir_direct_gathered_all": ([C.POINTER(vp), i32, C.POINTER(vp), i32, i32, C.POINTER(GBufferC), C.POINTER(RestirParamsC), u32], i32),
+            "rdh_comm_set_overlap": ([vp, i32], i32),
+            "rdh_comm_join": ([vp], i32),
             "rdh_allgather_tiles": ([vp, vp, vp], i32),
             "rdh_path_trace_gathered": ([vp, vp, vp, i32, i32, i32, u32], i32),
             "rdh_restir_exchange": ([vp], i32),
@@ -425,6 +428,41 @@ class Context:
 
     def restir_exchange(self):
         self.check(lib().rdh_restir_exchange(self.h))
+
+    def comm_set_overlap(self, enable):
+        """ReSTIR's exchanges on a communication stream beside rendering (default on) or on the render stream (off)."""
+        self.check(lib().rdh_comm_set_overlap(self.h, 1 if enable else 0))
+
+    def comm_join(self):
+        """The render stream waits for the exchanges in flight (before anything else reads G-buffer planes they complete)."""
+        self.check(lib().rdh_comm_join(self.h))
+
+    @staticmethod
+    def _all_error(ctxs, rc):
+        msgs = [lib().rdh_last_error(c.h) for c in ctxs]
+        raise RadishError(f"libradish_hip error {rc}: " + "; ".join(f"ctx {k}: {m.decode()}" for k, m in enumerate(msgs) if m))
+
+    @staticmethod
+    def gbuffer_exchange_all(ctxs, gb_cs):
+        n = len(ctxs)
+        arr = (C.c_void_p * n)(*[c.h for c in ctxs])
+        gbs = (GBufferC * n)(*gb_cs)
+        rc = lib().rdh_gbuffer_exchange_all(arr, n, gbs)
+        if rc != 0:
+            Context._all_error(ctxs, rc)
+
+    @staticmethod
+    def restir_direct_gathered_all(ctxs, direct_frames, iter, looper, gb_cs, reuse_mask, ris_count=32, num_spatial=5, temporal_clamp=20,
+                                   faithful_ris=1, flags=0):
+        n = len(ctxs)
+        arr = (C.c_void_p * n)(*[c.h for c in ctxs])
+        px = ctxs[0].width * ctxs[0].height * 3
+        d = (C.c_void_p * n)(*[c._ptr(t, px, "restir_direct_gathered_all") for c, t in zip(ctxs, direct_frames)])
+        gbs = (GBufferC * n)(*gb_cs)
+        p = RestirParamsC(reuse_mask, ris_count, num_spatial, temporal_clamp, faithful_ris)
+        rc = lib().rdh_restir_direct_gathered_all(arr, n, d, iter, looper, gbs, C.byref(p), flags)
+        if rc != 0:
+            Context._all_error(ctxs, rc)
 
     def restir_direct_gathered(self, direct_frame, iter, looper, gb_c, reuse_mask, ris_count=32, num_spatial=5, temporal_clamp=20,
                                faithful_ris=1, flags=0):

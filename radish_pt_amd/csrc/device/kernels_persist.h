@@ -179,15 +179,7 @@ __global__ __launch_bounds__(kScheduleThreads) void k_persist_schedule(unsigned 
 #define PH_MARK(i) do { } while (0)
 #define PH_COUNT(i, mask) do { } while (0)
 #endif
-// LOOK > 1 — the LATENCY form of the box loop, for launches with about as many pixels as the chip has lanes (a rank's share of
-// the frame on 4 or 8 GPUs): there the launch lasts as long as its longest PATH, a chain of ~10^3 dependent box steps
-// of one L2 round trip each, and the lanes are mostly idle.  A lane then requests the LOOK records that FOLLOW its position in
-// one go (threaded order = memory order) and walks through them without waiting again: a hit on an inner node continues with
-// the next record, a miss whose link lands inside the window continues there.  Same tests on the same records in the same
-// order — records fetched but not reached are neither tested nor counted — so results and counters are those of LOOK = 1.
-// The extra registers (8 per record) cost an occupancy step, which is why the bulk form stays LOOK = 1 (requesting both
-// successors was measured 7 % slower there: the L1 is the limiter).
-template <bool COUNT, int LOOK = 1>
+template <bool COUNT>
 __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
                                                        float *__restrict__ directIllum, float *__restrict__ indirectIllum,
                                                        PersistCounters *pc, const int *__restrict__ blockOrder,
@@ -438,7 +430,6 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                 do {
                     PH_COUNT(8, __ballot(walking));
                     waveSteps++;
-                    if (LOOK == 1) {
                     if (walking) {
                         // one VALU for the address: base (SGPRs) + 32-bit byte offset
                         const NodeRec *rec = reinterpret_cast<const NodeRec *>(nodeBase + (ordOfs + ((unsigned)node << 5)));
@@ -455,39 +446,14 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                         }
                         walking = pending < 0 && node != end;
                     }
-                    } else {
-                        // LOOK records per round trip (see the kernel's comment).  Index `end` is a readable pad record (layouts.h).
-                        float4 lo[LOOK], hi[LOOK];
-                        const int n0 = node;
-                        if (walking) {
-#pragma unroll
-                            for (int j = 0; j < LOOK; j++) {
-                                const int nj = (n0 + j) < end ? (n0 + j) : end;
-                                const NodeRec *rec = reinterpret_cast<const NodeRec *>(nodeBase + (ordOfs + ((unsigned)nj << 5)));
-                                lo[j] = rec->lo_prim;
-                                hi[j] = rec->hi_next;
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < LOOK; j++) {
-                            if (walking && node == n0 + j) {
-                                float boundDist;
-                                if (COUNT) ws.nodes++;
-                                const bool boundHit = aabbFastPk(lo[j], hi[j], rp, boundDist);
-                                if (boundHit && boundDist < tmax) {
-                                    pending = __float_as_int(lo[j].w);
-                                    node++;
-                                } else {
-                                    node = __float_as_int(hi[j].w);
-                                }
-                                walking = pending < 0 && node != end;
-                            }
-                        }
-                    }
                 } while (__popcll(ballotb(walking)) >= (minWalk > 1 ? minWalk : 1));
                 // (Requesting both successors ahead of the box test was measured and rejected: the L1 is busy ~80 % of
                 //  the launch — TCP_GATE_EN — and doubling its requests cost 7 % in the bulk and gained nothing in the
-                //  drain)
+                //  drain; DESIGN.md §7.  Round 3 tried the general form for SMALL launches — a rank's share of the frame on
+                //  4-8 GPUs, where the launch lasts one path latency: 2 / 4 / 8 records of the threaded order per round trip,
+                //  walked through without waiting again, bit-exact — and it lost there too (2.58 -> 3.38 / 3.53 / 6.41 ms per
+                //  rank at 8 ranks, profiles/r03_c_*): a draining wave is bound by instruction issue shared with its SIMD's
+                //  other waves, not by the round trip.)
             }
         }
         PH_MARK(2);

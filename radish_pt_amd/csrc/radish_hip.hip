@@ -27,14 +27,6 @@
 
 using namespace rd;
 
-#ifndef RD_PERSIST_LOOK
-#define RD_PERSIST_LOOK 4
-#endif
-#ifndef RD_PERSIST_LOOK_BLOCKS_PER_WAVE
-#define RD_PERSIST_LOOK_BLOCKS_PER_WAVE 3
-#endif
-constexpr int kPersistLook = RD_PERSIST_LOOK;  // records per round trip of k_pt_persistent's latency form
-constexpr int kPersistLookBlocksPerWave = RD_PERSIST_LOOK_BLOCKS_PER_WAVE;  // ... used when the launch has at most this many 8x8 blocks per resident wave
 constexpr int kWfParts = 3;  // sub-frame pipelines of the wavefront path (RDH_PT_WF_SUBFRAMES)
 
 struct rdh_ctx {
@@ -53,8 +45,7 @@ struct rdh_ctx {
     std::vector<void *> sceneAllocs;
     Counters *dCounters = nullptr;
     PersistCounters *dPersist = nullptr;
-    unsigned persistGrid = 0;      // resident waves of k_pt_persistent, bulk form
-    unsigned persistGridLook = 0;  // ... of its latency form (kernels_persist.h, LOOK > 1)
+    unsigned persistGrid = 0;
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
     unsigned wfGrid[4] = {0, 0, 0, 0};  // resident workgroups of k_wf_trace<false> / <true>, (unused), k_wf_shade
@@ -99,6 +90,14 @@ struct rdh_ctx {
     // RCCL communicator of this rank (rdh_comm_init) and the staging buffers of the collectives: this rank's packed tiles
     // (send side) and the gathered tiles of every rank (receive side), grown on demand
     void *comm = nullptr;
+    // ReSTIR's exchanges run on a communication stream of their own, so that the G-buffer gather overlaps pass 1's ray
+    // generation / walks / RIS and the reservoir gather overlaps the NEXT frame's G-buffer pass and pass 1.  Every
+    // collective of those entries is issued on commStream, in one order; the render stream and it hand over through events.
+    hipStream_t commStream = nullptr;
+    hipEvent_t evToComm = nullptr, evGbuf = nullptr, evImg = nullptr, evResv = nullptr;
+    bool commOverlap = true;   // rdh_comm_set_overlap
+    bool gbufPending = false;  // a G-buffer exchange is in flight on commStream: wait for evGbuf before the planes are read
+    bool resvPending = false;  // ... a reservoir exchange: wait for evResv before `last` reservoirs are read
     float *commSend[2] = {nullptr, nullptr};
     float *commRecv = nullptr;
     size_t commSendFloats[2] = {0, 0}, commRecvFloats = 0;
@@ -113,6 +112,9 @@ struct rdh_ctx {
 };
 
 namespace {
+
+int waitExchanges(rdh_ctx *c, bool gbuf, bool resv);  // defined with the collectives below
+int joinComm(rdh_ctx *c);
 
 int fail(rdh_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
@@ -498,6 +500,12 @@ void rdh_destroy(rdh_ctx *c) {
         hipStreamSynchronize(c->wfStream);
         hipStreamDestroy(c->wfStream);
     }
+    if (c->commStream) {
+        hipStreamSynchronize(c->commStream);
+        hipStreamDestroy(c->commStream);
+        for (hipEvent_t e : {c->evToComm, c->evGbuf, c->evImg, c->evResv})
+            if (e) hipEventDestroy(e);
+    }
     if (c->evWfJoin3) hipEventDestroy(c->evWfJoin3);
     if (c->evWfFork) hipEventDestroy(c->evWfFork);
     if (c->evWfJoin) hipEventDestroy(c->evWfJoin);
@@ -523,6 +531,8 @@ int rdh_set_stream(rdh_ctx *c, void *s) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->sideStream) HIP_TRY(c, hipStreamSynchronize(c->sideStream));
         if (c->wfStream) HIP_TRY(c, hipStreamSynchronize(c->wfStream));
+        if (c->commStream) HIP_TRY(c, hipStreamSynchronize(c->commStream));
+        c->gbufPending = c->resvPending = false;
         c->orderValid = false;
         c->stream = ns;
     }
@@ -532,6 +542,10 @@ int rdh_set_stream(rdh_ctx *c, void *s) {
 int rdh_synchronize(rdh_ctx *c) {
     if (!c) return RDH_ERR_ARGS;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->commStream) {  // exchanges that rdh_gbuffer_exchange / rdh_restir_direct_gathered left on the communication stream
+        HIP_TRY(c, hipStreamSynchronize(c->commStream));
+        c->gbufPending = c->resvPending = false;
+    }
     return RDH_OK;
 }
 
@@ -748,22 +762,13 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         // The grid must be fully resident: a workgroup that starts late would start its static first blocks late.
         unsigned groups = (((unsigned)(pm.numBlocks + 3) / 4 + 7u) / 8u) * 8u * 4u;  // one wave per workgroup
         if (c->persistGrid == 0) {
-            int perCU = 0, perCULook = 0, cus = 0;
-            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_pt_persistent<false, 1>), 64, 0));
-            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCULook, (k_pt_persistent<false, kPersistLook>), 64, 0));
+            int perCU = 0, cus = 0;
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_pt_persistent<false>, 64, 0));
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             if (perCU < 1) perCU = 1;
-            if (perCULook < 1) perCULook = 1;
             c->persistGrid = (unsigned)(perCU * cus);
-            c->persistGridLook = (unsigned)(perCULook * cus);
         }
-        // Which form of the box loop (kernels_persist.h): the LATENCY form (LOOK records per round trip) when the launch holds few
-        // pixels per resident lane — a rank's share of the frame on 4-8 GPUs — so that it lasts one path latency whatever the
-        // throughput; the bulk form otherwise.  RDH_PT_LOOKAHEAD / RDH_PT_NO_LOOKAHEAD force either (tests, measurements).
-        bool look = (unsigned long long)pm.numBlocks <= (unsigned long long)kPersistLookBlocksPerWave * (c->persistGridLook / (unsigned)c->share);
-        if (flags & RDH_PT_LOOKAHEAD) look = true;
-        if (flags & RDH_PT_NO_LOOKAHEAD) look = false;
-        unsigned residentGrid = (look ? c->persistGridLook : c->persistGrid) / (unsigned)c->share;
+        unsigned residentGrid = c->persistGrid / (unsigned)c->share;
         if (residentGrid < 8u) residentGrid = 8u;
         unsigned grid = groups < residentGrid ? groups : residentGrid;
         // longest-paths-first schedule from the previous launch's per-block costs (same partition and resolution only)
@@ -804,17 +809,11 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
         const int *order = useOrder ? c->blockOrder[cb] : nullptr;
         long pp = profBegin(c, flags);
-        if (count && look)
-            hipLaunchKernelGGL((k_pt_persistent<true, kPersistLook>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
-                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
-        else if (count)
-            hipLaunchKernelGGL((k_pt_persistent<true, 1>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
-                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
-        else if (look)
-            hipLaunchKernelGGL((k_pt_persistent<false, kPersistLook>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+        if (count)
+            hipLaunchKernelGGL(k_pt_persistent<true>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
                                maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
         else
-            hipLaunchKernelGGL((k_pt_persistent<false, 1>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+            hipLaunchKernelGGL(k_pt_persistent<false>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
                                maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
         profEnd(c, pp);
         // this launch's costs -> running means -> block order for launch n + 2, on the side stream
@@ -862,6 +861,7 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
     if (gb->width != c->cam.resx || gb->height != c->cam.resy)
         return fail(c, RDH_ERR_ARGS, "G-buffer %dx%d does not match camera %dx%d", gb->width, gb->height, c->cam.resx, c->cam.resy);
     HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = waitExchanges(c, true, false))) return rc;  // an exchange still writing `albedo` / `motion` (single-buffered planes)
     // ReSTIR needs the WHOLE frame's G-buffer on every rank: its temporal lookup follows motion vectors to arbitrary pixels
     // of the previous frame and its spatial lookup crosses tile borders.  Default on a partition: every rank renders the
     // whole frame (no exchange).  RDH_PT_PARTITION_GBUFFER: this rank renders the records of ITS tiles only (frame layout),
@@ -928,6 +928,8 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
 int rdh_restir_free(rdh_ctx *c) {
     if (!c) return RDH_ERR_ARGS;
     hipSetDevice(c->device);
+    if (c->commStream) hipStreamSynchronize(c->commStream);  // a reservoir exchange may still be writing `last`
+    c->resvPending = false;
     if (c->resvCur) hipFree(c->resvCur);
     if (c->resvLast) hipFree(c->resvLast);
     if (c->resvTemp) hipFree(c->resvTemp);
@@ -1009,6 +1011,7 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
         // lane-refill version of THAT kernel was measured slower (3.21 against 2.90 ms): the RIS loop dominates it.
         const unsigned p1Threads = 64;  // single-wave workgroups, one 8x8 block each (kernels_restir.h)
         const unsigned grid1 = ((nBlocks1 + 7u) / 8u) * 8u;
+        if ((rc = waitExchanges(c, true, true))) return rc;  // pass 1 reads the G-buffer and last frame's reservoirs (temporal reuse)
         if (flags & RDH_PT_COUNT)
             hipLaunchKernelGGL(k_restir_pass1<true>, dim3(grid1), dim3(p1Threads), 0, c->stream, c->ds, c->cam, pm, looper, iter, a, d_direct, apronBlocks);
         else
@@ -1062,6 +1065,10 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
             hipLaunchKernelGGL(k_restir_ris<false>, dim3(risGrid), dim3(kRisThreads), 0, c->stream, c->ds, c->cam, pm, looper, a, apronBlocks, sp);
         if ((rc = launchWalk(c, sp.segs, slots, nullptr, sp.occ, count, defer ? sp.deferCount + 1 : nullptr, sp.deferList + kRestirDeferCap, 1)))
             return rc;
+        // Only from here on are the G-buffer planes and last frame's reservoirs read (temporal reuse in the resolve step, spatial
+        // reuse in pass 2): exchanges of either that are still in flight on the communication stream have had the ray generation,
+        // both walks and the RIS launch to hide behind.
+        if ((rc = waitExchanges(c, true, true))) return rc;
         hipLaunchKernelGGL(k_restir_resolve, dim3(gridBlk), dim3(256), 0, c->stream, c->ds, pm, iter, a, apronBlocks, sp, d_direct);
     }
     if (p->reuseMask & 2)
@@ -1100,6 +1107,7 @@ int rdh_restir_read(rdh_ctx *c, int which, void *hostOut) {
     if (!c || !hostOut || which < 0 || which > 2) return RDH_ERR_ARGS;
     if (!c->resvCur) return fail(c, RDH_ERR_STATE, "ReSTIR not initialised");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->commStream) HIP_TRY(c, hipStreamSynchronize(c->commStream));
     const float *src = which == 0 ? c->resvCur : (which == 1 ? c->resvLast : c->resvTemp);
     HIP_TRY(c, hipMemcpy(hostOut, src, (size_t)c->restirPixels * 36, hipMemcpyDeviceToHost));
     return RDH_OK;
@@ -1197,6 +1205,7 @@ int commEnsure(rdh_ctx *c, float **buf, size_t *have, size_t floats) {
     if (*have >= floats) return RDH_OK;
     if (*buf) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->commStream) HIP_TRY(c, hipStreamSynchronize(c->commStream));
         hipFree(*buf);
         *buf = nullptr;
         *have = 0;
@@ -1205,6 +1214,48 @@ int commEnsure(rdh_ctx *c, float **buf, size_t *have, size_t floats) {
     *have = floats;
     return RDH_OK;
 }
+
+// ---- the communication stream of ReSTIR's exchanges ----
+int commStreamEnsure(rdh_ctx *c) {
+    if (c->commStream) return RDH_OK;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->commStream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->evToComm, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->evGbuf, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->evImg, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->evResv, hipEventDisableTiming));
+    return RDH_OK;
+}
+bool overlapOn(const rdh_ctx *c) { return c->commOverlap && c->commStream != nullptr; }
+// Launches between construction and destruction go to the communication stream (every helper launches on c->stream); with the
+// overlap switched off this is a no-op and everything stays on the render stream, in the same order.
+struct OnCommStream {
+    rdh_ctx *c;
+    hipStream_t saved;
+    explicit OnCommStream(rdh_ctx *ctx) : c(ctx), saved(ctx->stream) {
+        if (overlapOn(c)) c->stream = c->commStream;
+    }
+    ~OnCommStream() { c->stream = saved; }
+};
+// render stream -> communication stream: what was enqueued on the render stream so far happens before what follows on commStream
+int toComm(rdh_ctx *c) {
+    if (!overlapOn(c)) return RDH_OK;
+    HIP_TRY(c, hipEventRecord(c->evToComm, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->commStream, c->evToComm, 0));
+    return RDH_OK;
+}
+// the render stream waits for exchanges still in flight (before it reads G-buffer planes / `last` reservoirs they complete)
+int waitExchanges(rdh_ctx *c, bool gbuf, bool resv) {
+    if (gbuf && c->gbufPending) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evGbuf, 0));
+        c->gbufPending = false;
+    }
+    if (resv && c->resvPending) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evResv, 0));
+        c->resvPending = false;
+    }
+    return RDH_OK;
+}
+int joinComm(rdh_ctx *c) { return c ? waitExchanges(c, true, true) : RDH_OK; }
 
 // send: this rank's packed tiles, `channels` floats per pixel -> c->commRecv: the packed tiles of every rank, rank-major
 int gatherEnsure(rdh_ctx *c, int channels, const PixelMap &pm) {  // may allocate (and then synchronises): never inside a group
@@ -1290,6 +1341,8 @@ int rdh_comm_init_all(rdh_ctx **ctxs, int n) {
 int rdh_comm_destroy(rdh_ctx *c) {
     if (!c) return RDH_ERR_ARGS;
     hipSetDevice(c->device);
+    if (c->commStream) hipStreamSynchronize(c->commStream);
+    c->gbufPending = c->resvPending = false;
     if (c->comm) {
         hipStreamSynchronize(c->stream);
         g_rccl.CommDestroy(c->comm);
@@ -1397,33 +1450,140 @@ int rdh_path_trace_gathered_all(rdh_ctx **ctxs, int n, float *const *d_directFra
     return RDH_OK;
 }
 
-int rdh_restir_exchange(rdh_ctx *c) {
-    int rc = requireReady(c);
-    if (rc) return rc;
-    if (!c->resvLast) return fail(c, RDH_ERR_STATE, "ReSTIR not initialised");
-    HIP_TRY(c, hipSetDevice(c->device));
-    PixelMap pm = makePixelMap(c);
-    pm.packed = 1;
-    if ((rc = packFrame(c, c->resvLast, 0, 9, pm))) return rc;
-    if ((rc = allGatherPacked(c, c->commSend[0], 9, pm))) return rc;
-    return rdh_restir_exchange_unpack(c, c->commRecv);
-}
-
-int rdh_restir_direct_gathered(rdh_ctx *c, float *d_directFrame, int iter, int looper, const rdh_gbuffer *gb,
-                               const rdh_restir_params *p, uint32_t flags) {
+extern "C++" {
+namespace {
+// ---- ReSTIRDirect on a partition, in phases (so that the one-process form can put each collective of n contexts into one RCCL
+// group).  Render stream: pack the caller's image, the ReSTIR kernels.  Communication stream (overlap on; else the render stream):
+// image gather + un-tile, then the reservoir exchange for the NEXT frame's temporal reuse. ----
+int restirRender(rdh_ctx *c, float *d_directFrame, int iter, int looper, const rdh_gbuffer *gb, const rdh_restir_params *p, uint32_t flags) {
     int rc = requireReady(c);
     if (rc) return rc;
     if (!d_directFrame) return fail(c, RDH_ERR_ARGS, "rdh_restir_direct_gathered: null image");
     if (!c->comm) return fail(c, RDH_ERR_STATE, "no communicator: call rdh_comm_init first");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->commOverlap && (rc = commStreamEnsure(c))) return rc;
+    const PixelMap pm = packedMap(c);
+    const size_t shard = (size_t)pm.tilesPerRank * pm.tile * pm.tile;
+    if ((rc = commEnsure(c, &c->commSend[0], &c->commSendFloats[0], shard * 9))) return rc;  // allocations never happen inside a group
+    if ((rc = commEnsure(c, &c->commSend[1], &c->commSendFloats[1], shard * 3))) return rc;
+    if ((rc = gatherEnsure(c, 9, pm))) return rc;
     c->forcePacked = true;
-    PixelMap pm = makePixelMap(c);
-    if (!(rc = packFrame(c, d_directFrame, 1, 3, pm))) rc = rdh_restir_direct(c, c->commSend[1], iter, looper, gb, p, flags);
+    if (!(rc = packFrame(c, d_directFrame, 1, 3, makePixelMap(c)))) rc = rdh_restir_direct(c, c->commSend[1], iter, looper, gb, p, flags);
     c->forcePacked = false;
     if (rc) return rc;
-    if ((rc = allGatherPacked(c, c->commSend[1], 3, pm))) return rc;
-    if ((rc = rdh_untile(c, c->commRecv, d_directFrame))) return rc;
-    return rdh_restir_exchange(c);  // next frame's temporal reuse reads the whole frame's reservoirs
+    return toComm(c);
+}
+int restirImageGather(rdh_ctx *c) {
+    OnCommStream on(c);
+    return gatherEnqueue(c, c->commSend[1], 3, packedMap(c));
+}
+int restirImageEnd(rdh_ctx *c, float *d_directFrame) {  // + the send side of the reservoir exchange
+    OnCommStream on(c);
+    int rc = rdh_untile(c, c->commRecv, d_directFrame);
+    if (rc) return rc;
+    if (overlapOn(c)) HIP_TRY(c, hipEventRecord(c->evImg, c->commStream));
+    return packFrame(c, c->resvLast, 0, 9, packedMap(c));
+}
+int restirResvGather(rdh_ctx *c) {
+    OnCommStream on(c);
+    return gatherEnqueue(c, c->commSend[0], 9, packedMap(c));
+}
+int restirResvEnd(rdh_ctx *c, bool imageToo) {
+    {
+        OnCommStream on(c);
+        int rc = rdh_restir_exchange_unpack(c, c->commRecv);
+        if (rc) return rc;
+    }
+    if (overlapOn(c)) {
+        HIP_TRY(c, hipEventRecord(c->evResv, c->commStream));
+        c->resvPending = true;  // the next rdh_restir_direct waits where it first reads `last` reservoirs
+        // the caller's image is complete in render-stream order on return; the reservoir exchange goes on beside what comes next
+        if (imageToo) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evImg, 0));
+    }
+    return RDH_OK;
+}
+int checkAll(rdh_ctx **ctxs, int n, const char *what) {
+    if (!ctxs || n < 1) return RDH_ERR_ARGS;
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i]) return RDH_ERR_ARGS;
+    for (int i = 0; i < n; i++)
+        if (ctxs[i]->world != n || ctxs[i]->rank != i || !ctxs[i]->comm)
+            return fail(ctxs[i], RDH_ERR_STATE, "%s: context %d is rank %d of %d (rdh_comm_init_all first)", what, i, ctxs[i]->rank, ctxs[i]->world);
+    return RDH_OK;
+}
+// one RCCL group around `enqueue(ctx)` for every context
+template <typename F>
+int grouped(rdh_ctx **ctxs, int n, F enqueue) {
+    int r = g_rccl.GroupStart(), rc = RDH_OK;
+    if (r != 0) return rcclFail(ctxs[0], r, "ncclGroupStart");
+    for (int i = 0; i < n && rc == RDH_OK; i++) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) rc = fail(ctxs[i], RDH_ERR_NO_DEVICE, "hipSetDevice(%d)", ctxs[i]->device);
+        else rc = enqueue(ctxs[i]);
+    }
+    r = g_rccl.GroupEnd();  // always closed
+    if (rc) return rc;
+    if (r != 0) return rcclFail(ctxs[0], r, "ncclGroupEnd");
+    return RDH_OK;
+}
+}  // namespace
+}
+
+int rdh_restir_exchange(rdh_ctx *c) {
+    int rc = requireReady(c);
+    if (rc) return rc;
+    if (!c->resvLast) return fail(c, RDH_ERR_STATE, "ReSTIR not initialised");
+    if (!c->comm) return fail(c, RDH_ERR_STATE, "no communicator: call rdh_comm_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->commOverlap && (rc = commStreamEnsure(c))) return rc;
+    const PixelMap pm = packedMap(c);
+    if ((rc = commEnsure(c, &c->commSend[0], &c->commSendFloats[0], (size_t)pm.tilesPerRank * pm.tile * pm.tile * 9))) return rc;
+    if ((rc = gatherEnsure(c, 9, pm))) return rc;
+    if ((rc = toComm(c))) return rc;
+    {
+        OnCommStream on(c);
+        if ((rc = packFrame(c, c->resvLast, 0, 9, pm))) return rc;
+    }
+    if ((rc = restirResvGather(c))) return rc;
+    return restirResvEnd(c, false);
+}
+
+int rdh_restir_direct_gathered(rdh_ctx *c, float *d_directFrame, int iter, int looper, const rdh_gbuffer *gb,
+                               const rdh_restir_params *p, uint32_t flags) {
+    int rc = restirRender(c, d_directFrame, iter, looper, gb, p, flags);
+    if (rc) return rc;
+    if ((rc = restirImageGather(c))) return rc;
+    if ((rc = restirImageEnd(c, d_directFrame))) return rc;
+    if ((rc = restirResvGather(c))) return rc;  // next frame's temporal reuse reads the whole frame's reservoirs
+    return restirResvEnd(c, true);
+}
+
+int rdh_restir_direct_gathered_all(rdh_ctx **ctxs, int n, float *const *d_directFrames, int iter, int looper, const rdh_gbuffer *gbs,
+                                   const rdh_restir_params *p, uint32_t flags) {
+    int rc = checkAll(ctxs, n, "rdh_restir_direct_gathered_all");
+    if (rc) return rc;
+    if (!d_directFrames || !gbs) return RDH_ERR_ARGS;
+    for (int i = 0; i < n; i++)
+        if ((rc = restirRender(ctxs[i], d_directFrames[i], iter, looper, &gbs[i], p, flags))) return rc;
+    if ((rc = grouped(ctxs, n, restirImageGather))) return rc;
+    for (int i = 0; i < n; i++)
+        if ((rc = restirImageEnd(ctxs[i], d_directFrames[i]))) return rc;
+    if ((rc = grouped(ctxs, n, restirResvGather))) return rc;
+    for (int i = 0; i < n; i++)
+        if ((rc = restirResvEnd(ctxs[i], true))) return rc;
+    return RDH_OK;
+}
+
+int rdh_comm_set_overlap(rdh_ctx *c, int enable) {
+    if (!c) return RDH_ERR_ARGS;
+    int rc = rdh_synchronize(c);  // nothing of the other mode is left in flight
+    if (rc) return rc;
+    c->commOverlap = enable != 0;
+    return RDH_OK;
+}
+
+int rdh_comm_join(rdh_ctx *c) {
+    if (!c) return RDH_ERR_ARGS;
+    return joinComm(c);
 }
 
 extern "C++" {
@@ -1467,16 +1627,58 @@ int rdh_gbuffer_exchange_unpack(rdh_ctx *c, const rdh_gbuffer *gb, const float *
     return RDH_OK;
 }
 
-int rdh_gbuffer_exchange(rdh_ctx *c, const rdh_gbuffer *gb) {
+extern "C++" {
+namespace {
+int gbufExchangeBegin(rdh_ctx *c, const rdh_gbuffer *gb) {
     int rc = requireReady(c);
     if (rc) return rc;
     if (!c->comm) return fail(c, RDH_ERR_STATE, "no communicator: call rdh_comm_init first");
-    PixelMap pm = makePixelMap(c);
-    const size_t shard = (size_t)pm.tilesPerRank * pm.tile * pm.tile * 9;
-    if ((rc = commEnsure(c, &c->commSend[0], &c->commSendFloats[0], shard))) return rc;
-    if ((rc = rdh_gbuffer_exchange_pack(c, gb, c->commSend[0]))) return rc;
-    if ((rc = allGatherPacked(c, c->commSend[0], 9, pm))) return rc;
-    return rdh_gbuffer_exchange_unpack(c, gb, c->commRecv);
+    if ((rc = gbufCheck(c, gb, "rdh_gbuffer_exchange"))) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->commOverlap && (rc = commStreamEnsure(c))) return rc;
+    const PixelMap pm = packedMap(c);
+    if ((rc = commEnsure(c, &c->commSend[0], &c->commSendFloats[0], (size_t)pm.tilesPerRank * pm.tile * pm.tile * 9))) return rc;
+    if ((rc = gatherEnsure(c, 9, pm))) return rc;
+    if ((rc = toComm(c))) return rc;  // after the G-buffer pass that filled this rank's records
+    OnCommStream on(c);
+    return rdh_gbuffer_exchange_pack(c, gb, c->commSend[0]);
+}
+int gbufExchangeGather(rdh_ctx *c) {
+    OnCommStream on(c);
+    return gatherEnqueue(c, c->commSend[0], 9, packedMap(c));
+}
+int gbufExchangeEnd(rdh_ctx *c, const rdh_gbuffer *gb) {
+    {
+        OnCommStream on(c);
+        int rc = rdh_gbuffer_exchange_unpack(c, gb, c->commRecv);
+        if (rc) return rc;
+    }
+    if (overlapOn(c)) {
+        HIP_TRY(c, hipEventRecord(c->evGbuf, c->commStream));
+        c->gbufPending = true;  // rdh_restir_direct waits where it first reads the planes; other readers: rdh_comm_join
+    }
+    return RDH_OK;
+}
+}  // namespace
+}
+
+int rdh_gbuffer_exchange(rdh_ctx *c, const rdh_gbuffer *gb) {
+    int rc = gbufExchangeBegin(c, gb);
+    if (rc) return rc;
+    if ((rc = gbufExchangeGather(c))) return rc;
+    return gbufExchangeEnd(c, gb);
+}
+
+int rdh_gbuffer_exchange_all(rdh_ctx **ctxs, int n, const rdh_gbuffer *gbs) {
+    int rc = checkAll(ctxs, n, "rdh_gbuffer_exchange_all");
+    if (rc) return rc;
+    if (!gbs) return RDH_ERR_ARGS;
+    for (int i = 0; i < n; i++)
+        if ((rc = gbufExchangeBegin(ctxs[i], &gbs[i]))) return rc;
+    if ((rc = grouped(ctxs, n, gbufExchangeGather))) return rc;
+    for (int i = 0; i < n; i++)
+        if ((rc = gbufExchangeEnd(ctxs[i], &gbs[i]))) return rc;
+    return RDH_OK;
 }
 
 // RDH_PT_PERSISTENT on the ray-batch entries: the walk-only lane-refill kernel (device/kernels_walk.h); d_hits xor d_occ
@@ -1630,6 +1832,7 @@ int rdh_copy_image_to_pbo(rdh_ctx *c, void *d_pbo, const void *d_image, int widt
     if (!d_pbo || !d_image || width <= 0 || height <= 0 || kind < 0 || kind > 3 || toneMapping < 0 || toneMapping > 2)
         return fail(c, RDH_ERR_ARGS, "rdh_copy_image_to_pbo: bad arguments");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rj = joinComm(c)) return rj;  // d_image may be a G-buffer plane that an exchange is still completing
     long long total = (long long)width * height;
     hipLaunchKernelGGL(k_send_image_to_pbo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                        static_cast<uint32_t *>(d_pbo), d_image, width, height, kind, toneMapping, scale);
@@ -1641,6 +1844,7 @@ int rdh_copy_image_to_pbo(rdh_ctx *c, void *d_pbo, const void *d_image, int widt
 extern "C++" {
 namespace {
 int denoiseGB(rdh_ctx *c, const rdh_gbuffer *gb, DenoiseGB &d, const char *what) {
+    if (int rj = joinComm(c)) return rj;  // the planes may still be completed by an exchange on the communication stream
     if (!gb || !gb->albedo || !gb->motion || gb->frameIdx < 0 || gb->frameIdx > 1 || gb->width <= 0 || gb->height <= 0)
         return fail(c, RDH_ERR_ARGS, "%s: bad G-buffer", what);
     for (int k = 0; k < 2; k++)

@@ -19,6 +19,10 @@
 //          RADISH_SHIM_MULTI_GPU             pathTrace / ReSTIRDirect / GBuffer::render run on a tile partition over RCCL:
 //                                            call radish_shim::commInit(id, rank, world) once per process (one process per
 //                                            GPU); every rank then gets the whole frame, exactly as the single-GPU calls do
+//          RADISH_SHIM_ONE_PROCESS_GPUS      the same from ONE process driving n GPUs — the reference's own host model (one
+//                                            process, one frame loop, main.cpp:163-202): after DevScene::create call
+//                                            radish_shim::commInitAll(scene, sobol, n); the caller's images and G-buffer live on
+//                                            device 0 as today, devices 1..n-1 get mirrors the shim owns (needs hip_runtime_api.h)
 //
 // Error behaviour reproduces checkCUDAError (src/cudaUtil.h:16-34): print `HIP error (file:line): msg: text` and exit.
 #pragma once
@@ -51,8 +55,9 @@ inline void check(int rc, const char *msg, const char *file, int line) {
 
 // What DevScene::create does with a fully built `Scene` (src/scene.cpp:461-551): hand the host arrays to the device.
 template <typename SceneT>
-inline void devSceneCreate(const SceneT &scene, const uint32_t *sobol10kx200) {
-    if (!ctx()) RADISH_CHECK(rdh_create(&ctx(), 0), "rdh_create");
+inline void devSceneCreate(const SceneT &scene, const uint32_t *sobol10kx200, rdh_ctx *target = nullptr) {
+    if (!target && !ctx()) RADISH_CHECK(rdh_create(&ctx(), 0), "rdh_create");
+    if (!target) target = ctx();
     rdh_scene_desc d{};
     d.vertices = reinterpret_cast<const float *>(scene.meshData.vertices.data());
     d.normals = reinterpret_cast<const float *>(scene.meshData.normals.data());
@@ -80,7 +85,7 @@ inline void devSceneCreate(const SceneT &scene, const uint32_t *sobol10kx200) {
     d.envMapTexId = scene.envMapTexId;
     d.envMapSamplerLength = static_cast<int32_t>(scene.envMapSampler.binomDistribs.size());
     d.envMapSampler = scene.envMapSampler.binomDistribs.data();
-    RADISH_CHECK(rdh_scene_upload(ctx(), &d), "DevScene::create");
+    RADISH_CHECK(rdh_scene_upload(target, &d), "DevScene::create");
 }
 inline void devSceneDestroy() { RADISH_CHECK(rdh_scene_free(ctx()), "DevScene::destroy"); }
 
@@ -92,6 +97,58 @@ inline void commInit(const void *id128, int rank, int world, int device = -1) {
     if (!ctx()) RADISH_CHECK(rdh_create(&ctx(), device < 0 ? rank : device), "rdh_create");
     RADISH_CHECK(rdh_comm_init(ctx(), id128, rank, world), "rdh_comm_init");
 }
+
+#ifdef RADISH_SHIM_ONE_PROCESS_GPUS
+// ONE process, n GPUs.  Context 0 is ctx() on device 0 and works on the caller's buffers; every further device has
+// a context with the same scene and, owned here, whole-frame mirrors of what the caller keeps on device 0: two images and the
+// G-buffer planes.  Every device ends each call with the whole frame (tiles gathered over RCCL), so the running means and the
+// temporal reuse see on every device what the single-GPU calls would.
+struct Peer {
+    rdh_ctx *c = nullptr;
+    int device = 0;
+    float *direct = nullptr, *indirect = nullptr;
+    rdh_gbuffer gb{};
+};
+inline std::vector<Peer> &peers() {
+    static std::vector<Peer> p;
+    return p;
+}
+inline std::vector<rdh_ctx *> allContexts() {
+    std::vector<rdh_ctx *> v{ctx()};
+    for (Peer &p : peers()) v.push_back(p.c);
+    return v;
+}
+template <typename T>
+inline T *peerAlloc(int device, size_t n) {
+    void *ptr = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&ptr, n * sizeof(T)) != hipSuccess || hipMemset(ptr, 0, n * sizeof(T)) != hipSuccess)
+        check(RDH_ERR_NO_DEVICE, "hipMalloc (peer mirror)", __FILE__, __LINE__);
+    return static_cast<T *>(ptr);
+}
+template <typename SceneT>
+inline void commInitAll(const SceneT &scene, const uint32_t *sobol10kx200, int n) {
+    const size_t px = (size_t)scene.camera.resolution.x * (size_t)scene.camera.resolution.y;
+    for (int dev = 1; dev < n; dev++) {
+        Peer p;
+        p.device = dev;
+        RADISH_CHECK(rdh_create(&p.c, dev), "rdh_create (peer)");
+        devSceneCreate(scene, sobol10kx200, p.c);
+        p.direct = peerAlloc<float>(dev, 3 * px);
+        p.indirect = peerAlloc<float>(dev, 3 * px);
+        p.gb.albedo = peerAlloc<float>(dev, 3 * px);
+        p.gb.motion = peerAlloc<int32_t>(dev, px);
+        for (int k = 0; k < 2; k++) {
+            p.gb.normal[k] = peerAlloc<float>(dev, 3 * px);
+            p.gb.depth[k] = peerAlloc<float>(dev, px);
+            p.gb.primId[k] = peerAlloc<int32_t>(dev, px);
+        }
+        peers().push_back(p);
+    }
+    if (hipSetDevice(0) != hipSuccess) check(RDH_ERR_NO_DEVICE, "hipSetDevice", __FILE__, __LINE__);
+    std::vector<rdh_ctx *> all = allContexts();
+    RADISH_CHECK(rdh_comm_init_all(all.data(), (int)all.size()), "rdh_comm_init_all");
+}
+#endif
 
 template <typename GBufferT>
 inline rdh_gbuffer toC(const GBufferT &g) {
@@ -111,7 +168,19 @@ inline void pathTraceFree() {}
 inline void pathTrace(glm::vec3 *directIllum, glm::vec3 *indirectIllum, int iter) {
     rdh_ctx *c = radish_shim::ctx();
     RADISH_CHECK(rdh_set_camera(c, &State::scene->camera), "pathTrace");
-#ifdef RADISH_SHIM_MULTI_GPU
+#ifdef RADISH_SHIM_ONE_PROCESS_GPUS
+    std::vector<rdh_ctx *> all = radish_shim::allContexts();
+    std::vector<float *> dF{reinterpret_cast<float *>(directIllum)}, iF{reinterpret_cast<float *>(indirectIllum)};
+    for (radish_shim::Peer &p : radish_shim::peers()) {
+        RADISH_CHECK(rdh_set_camera(p.c, &State::scene->camera), "pathTrace");
+        dF.push_back(p.direct);
+        iF.push_back(p.indirect);
+    }
+    RADISH_CHECK(rdh_path_trace_gathered_all(all.data(), (int)all.size(), dF.data(), iF.data(), iter, State::looper, Settings::traceDepth,
+                                             RDH_PT_PERSISTENT),
+                 "pathTrace");
+    for (radish_shim::Peer &p : radish_shim::peers()) RADISH_CHECK(rdh_synchronize(p.c), "pathTrace");
+#elif defined(RADISH_SHIM_MULTI_GPU)
     RADISH_CHECK(rdh_path_trace_gathered(c, reinterpret_cast<float *>(directIllum), reinterpret_cast<float *>(indirectIllum), iter,
                                          State::looper, Settings::traceDepth, RDH_PT_PERSISTENT),
                  "pathTrace");
@@ -138,15 +207,43 @@ inline void ReSTIRInit() {
     rdh_ctx *c = radish_shim::ctx();
     RADISH_CHECK(rdh_set_camera(c, &State::scene->camera), "ReSTIRInit");
     RADISH_CHECK(rdh_restir_init(c), "ReSTIRInit");
+#ifdef RADISH_SHIM_ONE_PROCESS_GPUS
+    for (radish_shim::Peer &p : radish_shim::peers()) {
+        RADISH_CHECK(rdh_set_camera(p.c, &State::scene->camera), "ReSTIRInit");
+        RADISH_CHECK(rdh_restir_init(p.c), "ReSTIRInit");
+    }
+#endif
 }
-inline void ReSTIRFree() { RADISH_CHECK(rdh_restir_free(radish_shim::ctx()), "ReSTIRFree"); }
+inline void ReSTIRFree() {
+    RADISH_CHECK(rdh_restir_free(radish_shim::ctx()), "ReSTIRFree");
+#ifdef RADISH_SHIM_ONE_PROCESS_GPUS
+    for (radish_shim::Peer &p : radish_shim::peers()) RADISH_CHECK(rdh_restir_free(p.c), "ReSTIRFree");
+#endif
+}
 
 inline void ReSTIRDirect(glm::vec3 *directIllum, int iter, const GBuffer &gBuffer) {
     rdh_ctx *c = radish_shim::ctx();
     rdh_gbuffer g = radish_shim::toC(gBuffer);
     rdh_restir_params p{Settings::reservoirReuse, 32, 5, 20, 1};  // RESERVOIR_SIZE, restir.cu:87, :168, restir.h:21
     RADISH_CHECK(rdh_set_camera(c, &State::scene->camera), "ReSTIR Direct");
-#ifdef RADISH_SHIM_MULTI_GPU
+#ifdef RADISH_SHIM_ONE_PROCESS_GPUS
+    {
+        std::vector<rdh_ctx *> all = radish_shim::allContexts();
+        std::vector<float *> dF{reinterpret_cast<float *>(directIllum)};
+        std::vector<rdh_gbuffer> gbs{g};
+        for (radish_shim::Peer &p : radish_shim::peers()) {
+            RADISH_CHECK(rdh_set_camera(p.c, &State::scene->camera), "ReSTIR Direct");
+            p.gb.frameIdx = g.frameIdx;  // GBuffer::update stays the reference's: the mirrors follow the caller's G-buffer
+            std::memcpy(p.gb.lastCam, g.lastCam, sizeof(g.lastCam));
+            p.gb.width = g.width;
+            p.gb.height = g.height;
+            dF.push_back(p.direct);
+            gbs.push_back(p.gb);
+        }
+        RADISH_CHECK(rdh_restir_direct_gathered_all(all.data(), (int)all.size(), dF.data(), iter, State::looper, gbs.data(), &p, 0), "ReSTIR Direct");
+        for (radish_shim::Peer &q : radish_shim::peers()) RADISH_CHECK(rdh_synchronize(q.c), "ReSTIR Direct");
+    }
+#elif defined(RADISH_SHIM_MULTI_GPU)
     RADISH_CHECK(rdh_restir_direct_gathered(c, reinterpret_cast<float *>(directIllum), iter, State::looper, &g, &p, 0), "ReSTIR Direct");
 #else
     RADISH_CHECK(rdh_restir_direct(c, reinterpret_cast<float *>(directIllum), iter, State::looper, &g, &p, 0), "ReSTIR Direct");
@@ -174,7 +271,24 @@ inline void GBuffer::render(DevScene *, const Camera &cam) {
     rdh_ctx *c = radish_shim::ctx();
     rdh_gbuffer g = radish_shim::toC(*this);
     RADISH_CHECK(rdh_set_camera(c, &cam), "renderGBuffer");
-#ifdef RADISH_SHIM_MULTI_GPU  // this rank's tiles only, then one all-gather of 36 B per pixel
+#ifdef RADISH_SHIM_ONE_PROCESS_GPUS  // every device renders the records of ITS tiles, one grouped all-gather completes the planes
+    {
+        std::vector<rdh_ctx *> all = radish_shim::allContexts();
+        std::vector<rdh_gbuffer> gbs{g};
+        RADISH_CHECK(rdh_gbuffer_render(c, &g, RDH_PT_PARTITION_GBUFFER), "renderGBuffer");
+        for (radish_shim::Peer &p : radish_shim::peers()) {
+            RADISH_CHECK(rdh_set_camera(p.c, &cam), "renderGBuffer");
+            p.gb.frameIdx = g.frameIdx;
+            std::memcpy(p.gb.lastCam, g.lastCam, sizeof(g.lastCam));
+            p.gb.width = g.width;
+            p.gb.height = g.height;
+            RADISH_CHECK(rdh_gbuffer_render(p.c, &p.gb, RDH_PT_PARTITION_GBUFFER), "renderGBuffer");
+            gbs.push_back(p.gb);
+        }
+        RADISH_CHECK(rdh_gbuffer_exchange_all(all.data(), (int)all.size(), gbs.data()), "renderGBuffer");
+        for (radish_shim::Peer &p : radish_shim::peers()) RADISH_CHECK(rdh_synchronize(p.c), "renderGBuffer");
+    }
+#elif defined(RADISH_SHIM_MULTI_GPU)  // this rank's tiles only, then one all-gather of 36 B per pixel
     RADISH_CHECK(rdh_gbuffer_render(c, &g, RDH_PT_PARTITION_GBUFFER), "renderGBuffer");
     RADISH_CHECK(rdh_gbuffer_exchange(c, &g), "renderGBuffer");
 #else

@@ -16,9 +16,8 @@ sd = bench.make_scene(scene)
 cam = bench.make_camera(scene, W, H)
 dev = torch.device("cuda", 0)
 out = {"scene": scene, "W": W, "H": H, "depth": depth, "rows": []}
-EXTRA = {"persistent_bulk": api.RDH_PT_PERSISTENT | api.RDH_PT_NO_LOOKAHEAD, "persistent_latency": api.RDH_PT_PERSISTENT | api.RDH_PT_LOOKAHEAD}
-for mode in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("wavefront_sort2", "persistent", "persistent_bulk", "persistent_latency")):
-    flags = EXTRA[mode] if mode in EXTRA else bench.mode_flags(api, mode)
+for mode in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("wavefront_sort2", "wavefront_sort", "persistent")):
+    flags = bench.mode_flags(api, mode)
     for world in (1, 2, 4, 8):
         worst = None
         for rank in sorted({0, world // 2, world - 1}):

@@ -127,14 +127,21 @@ struct SpatioTemporalFilter {
 #ifdef SHIM_CHECK_MULTI_GPU
 #define RADISH_SHIM_MULTI_GPU
 #endif
+#ifdef SHIM_CHECK_ONE_PROCESS
+#define RADISH_SHIM_ONE_PROCESS_GPUS
+#endif
 #include "radish_shim.hpp"
 
 // use everything once, so that templates are instantiated and overloads resolved
 void shim_syntax_check_uses(Scene &scene, GBuffer &gb, glm::vec3 *img, glm::vec3 *img2, uchar4 *pbo, const uint32_t *sobol) {
     radish_shim::devSceneCreate(scene, sobol);
+#ifdef SHIM_CHECK_ONE_PROCESS
+    radish_shim::commInitAll(scene, sobol, 2);
+#else
     unsigned char id[128];
     radish_shim::commUniqueId(id);
     radish_shim::commInit(id, 0, 1);
+#endif
     pathTraceInit();
     pathTrace(img, img2, 0);
     pathTraceDirect(img, 0);

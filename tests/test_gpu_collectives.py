@@ -146,17 +146,22 @@ def test_one_process_two_gpus(cornell_small):
             c.close()
 
 
-def test_rccl_one_rank_restir_gathered():
+@pytest.mark.parametrize("mode", ["overlap", "render_stream", "overlap_no_host_sync", "one_process_all"])
+def test_rccl_one_rank_restir_gathered(mode):
     """ReSTIRDirect for N GPUs at N = 1: partitioned G-buffer + rdh_gbuffer_exchange, rdh_restir_direct_gathered (image
-    all-gather + reservoir exchange inside), three frames with a moving camera: G-buffer planes, images and reservoirs equal
-    the plain single-GPU calls."""
+    all-gather + reservoir exchange inside), frames with a moving camera: G-buffer planes, images and reservoirs equal the plain
+    single-GPU calls.  overlap (default): the exchanges run on the context's communication stream beside the rendering;
+    render_stream: rdh_comm_set_overlap(0); overlap_no_host_sync: four frames enqueued back to back with no host synchronisation
+    in between, so that only the events order the reservoir / G-buffer exchanges against the next frame's kernels;
+    one_process_all: the same through rdh_comm_init_all + the *_all entries (one RCCL group per collective)."""
     from radish_pt_amd import api, hostlib, scenes
 
     torch = _torch()
     sd = scenes.teapots(segments=12, bands=8, grid=2, emissive_grid=(4, 8))
     W, H = 150, 90
     n = W * H
-    cams = [hostlib.make_camera(W, H, eye=(0.3 + 0.08 * f, 1.9, 7.4), rotation=(-91.5, -11.0, 0.0), fovy=19.0) for f in range(3)]
+    nframes = 4 if mode == "overlap_no_host_sync" else 3
+    cams = [hostlib.make_camera(W, H, eye=(0.3 + 0.08 * f, 1.9, 7.4), rotation=(-91.5, -11.0, 0.0), fovy=19.0) for f in range(nframes)]
     ref_ctx, ctx = api.Context(0), api.Context(0)
     try:
         for c in (ref_ctx, ctx):
@@ -164,7 +169,12 @@ def test_rccl_one_rank_restir_gathered():
             c.set_camera(cams[0])
             c.restir_init()
         ctx.set_partition(0, 1, 32)
-        ctx.comm_init(api.Context.comm_unique_id(), 0, 1)
+        if mode == "one_process_all":
+            api.Context.comm_init_all([ctx])
+        else:
+            ctx.comm_init(api.Context.comm_unique_id(), 0, 1)
+        if mode == "render_stream":
+            ctx.comm_set_overlap(False)
         gb_ref, gb = api.GBuffer(), api.GBuffer()
         gb_ref.create(W, H)
         gb.create(W, H)
@@ -174,21 +184,33 @@ def test_rccl_one_rank_restir_gathered():
             ctx.set_camera(cam)
             ref_ctx.gbuffer_render(gb_ref.c_struct(cam_fallback=cam), 0)
             ctx.gbuffer_render(gb.c_struct(cam_fallback=cam), api.RDH_PT_PARTITION_GBUFFER)
-            ctx.gbuffer_exchange(gb.c_struct(cam_fallback=cam))
-            ctx.synchronize()
-            ref_ctx.synchronize()
-            k = gb.frameIdx
-            for a, b, plane in ((gb.albedo, gb_ref.albedo, "albedo"), (gb.normal[k], gb_ref.normal[k], "normal"),
-                                (gb.depth[k], gb_ref.depth[k], "depth"), (gb.primId[k], gb_ref.primId[k], "primId"),
-                                (gb.motion, gb_ref.motion, "motion")):
-                assert np.array_equal(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32)), f"frame {f}: {plane}"
+            if mode == "one_process_all":
+                api.Context.gbuffer_exchange_all([ctx], [gb.c_struct(cam_fallback=cam)])
+            else:
+                ctx.gbuffer_exchange(gb.c_struct(cam_fallback=cam))
+            if mode != "overlap_no_host_sync":
+                ctx.synchronize()
+                ref_ctx.synchronize()
+                k = gb.frameIdx
+                for a, b, plane in ((gb.albedo, gb_ref.albedo, "albedo"), (gb.normal[k], gb_ref.normal[k], "normal"),
+                                    (gb.depth[k], gb_ref.depth[k], "depth"), (gb.primId[k], gb_ref.primId[k], "primId"),
+                                    (gb.motion, gb_ref.motion, "motion")):
+                    assert np.array_equal(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32)), f"frame {f}: {plane}"
             ref_ctx.restir_direct(img_ref, 0, 40 + f, gb_ref.c_struct(cam), 3)
-            ctx.restir_direct_gathered(img, 0, 40 + f, gb.c_struct(cam), 3)
-            ctx.synchronize()
-            assert_bit_equal(img.cpu().numpy(), img_ref.cpu().numpy(), f"ReSTIR gathered, frame {f}")
-            assert ctx.restir_read(1).tobytes() == ref_ctx.restir_read(1).tobytes(), f"reservoirs, frame {f}"
+            if mode == "one_process_all":
+                api.Context.restir_direct_gathered_all([ctx], [img], 0, 40 + f, [gb.c_struct(cam)], 3)
+            else:
+                ctx.restir_direct_gathered(img, 0, 40 + f, gb.c_struct(cam), 3)
+            if mode != "overlap_no_host_sync":
+                ctx.synchronize()
+                assert_bit_equal(img.cpu().numpy(), img_ref.cpu().numpy(), f"ReSTIR gathered, frame {f}")
+                assert ctx.restir_read(1).tobytes() == ref_ctx.restir_read(1).tobytes(), f"reservoirs, frame {f}"
             gb_ref.update(cam)
             gb.update(cam)
+        ctx.synchronize()
+        ref_ctx.synchronize()
+        assert_bit_equal(img.cpu().numpy(), img_ref.cpu().numpy(), "ReSTIR gathered, last frame")
+        assert ctx.restir_read(1).tobytes() == ref_ctx.restir_read(1).tobytes(), "reservoirs, last frame"
         assert float(img_ref.max()) > 0
     finally:
         ctx.close()

@@ -47,8 +47,7 @@ def test_config1_cornell_400x400_depth4_16spp(gpu_ctx, cornell_full):
     gpu_ctx.set_partition(0, 1, 64)
     gpu_ctx.upload_scene(cornell_full)
     gpu_ctx.set_camera(cam)
-    for name, flags in (("persistent", api.RDH_PT_PERSISTENT), ("persistent, bulk form", api.RDH_PT_PERSISTENT | api.RDH_PT_NO_LOOKAHEAD),
-                        ("persistent, latency form", api.RDH_PT_PERSISTENT | api.RDH_PT_LOOKAHEAD), ("megakernel", api.RDH_PT_MEGAKERNEL),
+    for name, flags in (("persistent", api.RDH_PT_PERSISTENT), ("megakernel", api.RDH_PT_MEGAKERNEL),
                         ("wavefront+sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL),
                         ("wavefront+sort, sub-frames", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES),
                         # the per-stage lists of literal-class rays cut to 4 entries: what does not fit stays in the ordinary queues
@@ -84,14 +83,13 @@ def test_config3_teapots_1080p_wavefront_sort(gpu_ctx):
     for name, flags in (("sort", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL), ("wave", api.RDH_PT_WAVEFRONT),
                         ("sort2", api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_WF_SUBFRAMES),
                         ("wave2", api.RDH_PT_WAVEFRONT | api.RDH_PT_WF_SUBFRAMES),
-                        ("persist", api.RDH_PT_PERSISTENT), ("persist_latency", api.RDH_PT_PERSISTENT | api.RDH_PT_LOOKAHEAD),
-                        ("mega", api.RDH_PT_MEGAKERNEL)):
+                        ("persist", api.RDH_PT_PERSISTENT), ("mega", api.RDH_PT_MEGAKERNEL)):
         d = torch.zeros(W * H, 3, device="cuda")
         i = torch.zeros(W * H, 3, device="cuda")
         gpu_ctx.counters_reset()
         gpu_ctx.path_trace(d, i, 0, 3, depth, flags | api.RDH_PT_COUNT)
         out[name] = (d.cpu().numpy(), i.cpu().numpy(), gpu_ctx.counters())
-    for name in ("wave", "sort2", "wave2", "persist", "persist_latency", "mega"):
+    for name in ("wave", "sort2", "wave2", "persist", "mega"):
         assert_bit_equal(out[name][0], out["sort"][0], f"config 3: {name} vs sorted wavefront, direct")
         assert_bit_equal(out[name][1], out["sort"][1], f"config 3: {name} vs sorted wavefront, indirect")
         assert out[name][2] == out["sort"][2], name

@@ -199,18 +199,15 @@ def test_workgroup_per_ray_trace_bit_exact(cornell_gpu, cornell_small):
 # ---------------------------------------------------------------------------------------------------------------------
 # pathTrace: megakernel and wavefront, several frames of accumulation
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("flags_name", ["mega", "wavefront", "wavefront_sort", "persistent", "persistent_bulk", "persistent_latency"])
+@pytest.mark.parametrize("flags_name", ["mega", "wavefront", "wavefront_sort", "persistent"])
 @pytest.mark.parametrize("size,depth", [((64, 48), 4), ((37, 29), 8)])
 def test_path_trace_bit_exact(cornell_gpu, cornell_small, flags_name, size, depth):
     from radish_pt_amd import api, scenes
 
     torch = _torch()
-    # persistent: the form of the box loop is chosen by launch size (these frames are small: the latency form); _bulk / _latency
-    # force one record per step / several records per round trip (kernels_persist.h, LOOK)
     flags = {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
              "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,
-             "persistent": api.RDH_PT_PERSISTENT, "persistent_bulk": api.RDH_PT_PERSISTENT | api.RDH_PT_NO_LOOKAHEAD,
-             "persistent_latency": api.RDH_PT_PERSISTENT | api.RDH_PT_LOOKAHEAD}[flags_name] | api.RDH_PT_COUNT
+             "persistent": api.RDH_PT_PERSISTENT}[flags_name] | api.RDH_PT_COUNT
     W, H = size
     cam = scenes.cornell_camera(W, H)
     o = _oracle(cornell_small)
