@@ -17,6 +17,7 @@
 // heads (one returning atomic per packet), so no queue length ever travels to the host.
 #pragma once
 #include "kernels_pt.h"
+#include "wg_trace.h"
 
 namespace rd {
 
@@ -104,6 +105,11 @@ RD_DEV int wavePull(int *head, int packet = kPacket) {
     if ((threadIdx.x & 63u) == 0u) base = atomicAdd(head, packet);
     return __shfl(base, 0, 64) + gridWaves() * packet;
 }
+// (Round 3 measured GUIDED self-scheduling — after the static packet a pull reserves an even share of half the items still
+// unreserved, 32..128 for k_wf_trace, 64..packet for k_wf_shade, since a stage hands every wave only two or three fixed packets —
+// and rejected it: teapots 9.07 -> 9.08 ms sorted / 8.90 -> 8.95 unsorted with three sub-frames, one pipeline 11.2 -> 11.8; the
+// extra returning atomics cost what the finer tail saves, and with three pipelines a stage's tail is filled by the others anyway.
+// profiles/r03_f_experiment_guided_scheduling.txt)
 
 // ---- raygen ---------------------------------------------------------------------------------------------------
 // Sub-frames: the wavefront pipeline can run as H independent pipelines over interleaved block sets (block b belongs to
@@ -180,20 +186,74 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
     v2 hitBary = mk2(0.f, 0.f);
     bool occluded = false;
 
-    // Rays that shade(k-1) found to look literal-class (they wander through the tree for thousands of box steps and are traced by
-    // the whole wave, 90 us median on the teapots scene) start FIRST, one per wave, lane by lane: picked up with a late packet one
-    // of them is what the stage ends on (measured ceiling: 0.5-0.95 ms of the teapots frame).
+    // Rays that shade(k-1) found to look literal-class (they wander through the tree for thousands of box steps; one wave needs 90 us
+    // (median) to 1.5 ms for one of them on the teapots scene) start FIRST: picked up with a late packet one of them is what the stage
+    // ends on (measured ceiling: 0.5-0.95 ms of the teapots frame).  Round 3: the workgroup traces them TOGETHER — its four waves are
+    // at the same point only here, before each goes its own way with lane refill — 256 records per round trip with the parallel
+    // resolve of wg_trace.h instead of 64 with a scalar one (coopTraceWhole): entry `it` of the list belongs to workgroup it % grid.
+    // The list is a HINT (shade classifies by the direction it emits, this kernel by the ray it builds): an entry whose ray turns out
+    // ordinary is left to a lane of the workgroup (first round below), as before.
+    __shared__ WgTraceSharedT<256> wgsh;
+    const int nLit = c->litCount[k].v < w.litCap ? c->litCount[k].v : w.litCap;
+    for (int it = int(blockIdx.x); it < nLit; it += int(gridDim.x)) {  // uniform over the workgroup
+        const int e = w.litq[k & 1][it];
+        const bool sh = (e & kWfLitShadow) != 0;
+        const int pp = e & (kWfLitShadow - 1);
+        Ray ray;
+        float lim;
+        if (sh) {
+            const float4 x4 = w.prevPos[pp], y4 = w.sht[pp];
+            const v3 x = mk3(x4.x, x4.y, x4.z), y = mk3(y4.x, y4.y, y4.z);
+            v3 dir = y - x;  // DevScene::testOcclusion's ray set-up (scene.h:304-311)
+            const float dist = length(dir);
+            dir = dir / dist;
+            lim = dist - 1e-4f;
+            ray = makeOffsetedRay(x, dir);
+        } else {
+            const float4 o = w.ro[pp], d = w.rd[pp];
+            ray = Ray{mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z)};
+            lim = 3.402823466e+38f;
+        }
+        const RaySlab urs = makeRaySlab(ray);
+        if (urs.cls == 0 || end == 0) continue;  // the hint did not hold: a lane takes this entry below
+        const NodeRec *un = s.nodes[getMTBVHId(-ray.d)];
+        const CoopTrace ct = sh ? wgTraceWhole<true, 256>(s, un, urs, lim, wgsh) : wgTraceWhole<false, 256>(s, un, urs, lim, wgsh);
+        if (threadIdx.x == 0) {  // the record of the finished ray (as in the retire step of the loop below)
+            if (sh) {
+                nAny++;
+                const float4 n = w.nee[pp];
+                if (!ct.found && n.w >= 0.f) {  // the addition sampleDirectLight's caller makes (pathtrace.cu:201-207)
+                    float4 *acc = n.w == 0.f ? w.accD : w.accI;
+                    const float4 a = acc[pp];
+                    acc[pp] = make_float4(a.x + n.x, a.y + n.y, a.z + n.z, 0.f);
+                }
+            } else {
+                nClosest++;
+                const bool hit = ct.hitPrim != -1;
+                if (hit) nHits++;
+                w.hit[pp] = make_int4(ct.hitPrim, __float_as_int(hit ? ct.bary.x : 0.f), __float_as_int(hit ? ct.bary.y : 0.f),
+                                      hit ? int(s.primClass[ct.hitPrim]) : 0);
+            }
+            if (COUNT) {
+                ws.nodes += ct.nodes;
+                ws.tris += ct.tris;
+            }
+        }
+    }
     bool firstRound = true;
+    bool fromList = false;  // this lane's item of the first round came from the list: skip it if the workgroup has traced it above
     for (;;) {
         // ---- hand new items to idle lanes ----
         bool doStart = false;  // this lane takes an item in this round: kind and path slot go straight into isShadow / p
+        fromList = false;
         if (firstRound) {
             firstRound = false;
-            const int nLit = c->litCount[k].v < w.litCap ? c->litCount[k].v : w.litCap;
-            const int it = globalWave() + int(threadIdx.x & 63u) * gridWaves();
+            // the workgroup's j-th entry (j = 4 * lane + wave of the workgroup: at most 256 per workgroup) — see above
+            const int it = int(blockIdx.x) + (int(threadIdx.x & 63u) * 4 + int(threadIdx.x >> 6)) * int(gridDim.x);
             if (it < nLit) {
                 const int e = w.litq[k & 1][it];
                 doStart = true;
+                fromList = true;
                 isShadow = (e & kWfLitShadow) != 0;
                 p = e & (kWfLitShadow - 1);
             }
@@ -252,6 +312,12 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
                 hitPrim = -1;
                 occluded = false;
                 alive = node != end;
+                if (fromList && rs.cls != 0 && end != 0) {  // traced (and counted, and retired) by the workgroup above
+                    if (isShadow) nAny--;
+                    else nClosest--;
+                    alive = false;
+                    p = -1;
+                }
             }
         }
         unsigned long long am = __ballot(alive);

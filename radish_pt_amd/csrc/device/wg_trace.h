@@ -20,19 +20,25 @@ namespace rd {
 constexpr int kWgTraceThreads = 1024;
 constexpr int kWgTraceWords = kWgTraceThreads / 64;
 
-struct WgTraceShared {
-    int4 jump[kWgTraceThreads];  // {where the walk is after the records it passes from here, boxes visited, triangles tested, -}
-    int prim[kWgTraceThreads];
-    float dist[kWgTraceThreads], bu[kWgTraceThreads], bv[kWgTraceThreads];
+// THREADS = workgroup size = records per window: 1 024 for the launches that give a ray a workgroup of its own (G-buffer, ReSTIR's
+// set-aside lists), 256 inside k_wf_trace, whose 4-wave workgroups trace the stage's literal-class list together before their waves
+// go their own ways (kernels_wave.h).
+template <int THREADS>
+struct WgTraceSharedT {
+    int4 jump[THREADS];  // {where the walk is after the records it passes from here, boxes visited, triangles tested, -}
+    int prim[THREADS];
+    float dist[THREADS], bu[THREADS], bv[THREADS];
     float tmax, baryU, baryV;
     int node, cur, hitPrim, found, state;  // state: 0 window left (node set), 1 hit accepted (cur set, jump table stale)
     unsigned nodes, tris;
 };
+using WgTraceShared = WgTraceSharedT<kWgTraceThreads>;
 
 constexpr int kWgAccept = 0x40000000;  // jump target: "stopped on record (target & 0xffff), whose triangle is accepted"
 
-template <bool ANY>
-RD_DEV CoopTrace wgTraceWhole(const DScene &s, const NodeRec *nodes, const RaySlab &u, float tLimit, WgTraceShared &sh) {
+template <bool ANY, int THREADS = kWgTraceThreads>
+RD_DEV CoopTrace wgTraceWhole(const DScene &s, const NodeRec *nodes, const RaySlab &u, float tLimit, WgTraceSharedT<THREADS> &sh) {
+    constexpr int kWgTraceThreads = THREADS;  // (shadows the launch constant: everything below is per window of THREADS records)
     const int tid = int(threadIdx.x);
     const int lane = tid & 63, w = tid >> 6;
     const int end = s.bvhSize;
