@@ -55,6 +55,8 @@ struct WaveWorkspace {
     int *shadowq;
     int *litq[2];     // path slots of rays that look literal-class (bit 30: a shadow ray); trace(k) starts them first, one per wave
     int litCap;       // entries a stage may hold: min(kWfLitCap, 64 * waves of the trace grid)
+    int *treeOvf;     // k_wf_trace<.., true>: the deep end of its lanes' stacks, [wave of the grid][treeOvfDepth][64] (traverse.h, treeBoxStep)
+    int treeOvfDepth;
     WaveCounters *ctr;
 };
 
@@ -156,8 +158,15 @@ __global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelM
 #define RD_WF_COOP_LONE 1
 #endif
 
-template <bool COUNT>
-__global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int k) {
+// TREE: the per-lane walks go over the shared tree (DScene::tree: one 32-byte record per node for all six orderings, pending far
+// children on a per-lane stack in LDS; traverse.h, treeBoxStep) instead of the six threaded arrays — same visits in the same order.
+// Chosen by the host for big scenes (radish_hip.hip, useTree): closest-hit walks of mixed directions gain ~20 % from the six-fold
+// smaller node footprint, the shadow walks (one direction class, so one threaded array anyway) pay ~5 % for the stack.
+#ifndef RD_WF_TREE_WAVES
+#define RD_WF_TREE_WAVES 7  // waves per SIMD the tree variant is held to (its 79 VGPRs would leave 6)
+#endif
+template <bool COUNT, bool TREE = false>
+__global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_wf_trace(DScene s, WaveWorkspace w, int k) {
     WaveCounters *c = w.ctr;
     const int nShadow = (k > 0) ? c->shadowCount[k - 1].v : 0;
     const int nRay = c->rayCount[k].v;
@@ -166,6 +175,7 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
     const int end = s.bvhSize;
+    const int END = TREE ? kTreeEnd : end;  // `node` of a finished walk
 
     // wave-uniform reservation of work items; the first one is static (see wavePull)
     int resNext = globalWave() * kPacket, resEnd = resNext + kPacket;
@@ -179,8 +189,9 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
     RaySlab rs;
     rs.o = rs.d = rs.inv = mk3(0.f);
     rs.cls = 0;
-    const NodeRec *nodes = s.nodes[0];
-    int node = end, pending = -1;
+    const NodeRec *nodes = s.nodes[0];  // !TREE: the ray's threaded array
+    int ord = 0, sp = 1, tos = kTreeEnd;  // TREE: the ray's ordering, its stack (treeBoxStep)
+    int node = END, pending = -1;
     float tmax = 0.f;
     int hitPrim = -1;
     v2 hitBary = mk2(0.f, 0.f);
@@ -193,7 +204,15 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
     // resolve of wg_trace.h instead of 64 with a scalar one (coopTraceWhole): entry `it` of the list belongs to workgroup it % grid.
     // The list is a HINT (shade classifies by the direction it emits, this kernel by the ray it builds): an entry whose ray turns out
     // ordinary is left to a lane of the workgroup (first round below), as before.
-    __shared__ WgTraceSharedT<256> wgsh;
+    // (TREE: the four waves' stack rows take over the workgroup trace's LDS once the list is done)
+    constexpr int kStackInts = TREE ? 4 * kTreeLds * 64 : 1;
+    __shared__ union WfTraceLds {
+        WgTraceSharedT<256> wg;
+        int stack[kStackInts];
+    } lds;
+    WgTraceSharedT<256> &wgsh = lds.wg;
+    int *const stk = lds.stack + (TREE ? int(threadIdx.x >> 6) * kTreeLds * 64 : 0);
+    int *const ovf = TREE ? w.treeOvf + (size_t)globalWave() * (size_t)w.treeOvfDepth * 64 : nullptr;
     const int nLit = c->litCount[k].v < w.litCap ? c->litCount[k].v : w.litCap;
     for (int it = int(blockIdx.x); it < nLit; it += int(gridDim.x)) {  // uniform over the workgroup
         const int e = w.litq[k & 1][it];
@@ -239,6 +258,10 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
                 ws.tris += ct.tris;
             }
         }
+    }
+    if (TREE) {
+        __syncthreads();  // every wave is done with the workgroup trace's LDS
+        stk[threadIdx.x & 63u] = kTreeEnd;  // row 0: what a walk pops last
     }
     bool firstRound = true;
     bool fromList = false;  // this lane's item of the first round came from the list: skip it if the workgroup has traced it above
@@ -306,12 +329,18 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
             }
             if (p >= 0) {
                 rs = makeRaySlab(ray);
-                nodes = s.nodes[getMTBVHId(-ray.d)];
-                node = 0;
+                if (TREE) {
+                    ord = getMTBVHId(-ray.d);
+                    sp = 1;
+                    tos = kTreeEnd;
+                } else {
+                    nodes = s.nodes[getMTBVHId(-ray.d)];
+                }
+                node = end != 0 ? 0 : END;
                 pending = -1;
                 hitPrim = -1;
                 occluded = false;
-                alive = node != end;
+                alive = node != END;
                 if (fromList && rs.cls != 0 && end != 0) {  // traced (and counted, and retired) by the workgroup above
                     if (isShadow) nAny--;
                     else nClosest--;
@@ -328,12 +357,12 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
 
         // ---- literal-class rays: traced whole by the whole wave (traverse.h, coopTraceWhole) ----
         {
-            unsigned long long lit = __ballot(alive && rs.cls != 0 && node == 0 && pending < 0);
+            unsigned long long lit = __ballot(alive && rs.cls != 0 && node == 0 && pending < 0 && (!TREE || (sp == 1 && tos == kTreeEnd)));
             while (lit) {
                 const int L = __ffsll((long long)lit) - 1;
                 lit &= lit - 1ull;
                 const bool shadowL = readlaneI(isShadow ? 1 : 0, L) != 0;
-                const NodeRec *un = readlanePtr(nodes, L);
+                const NodeRec *un = TREE ? s.nodes[0] + (size_t)readlaneI(ord, L) * (size_t)(end + 1) : readlanePtr(nodes, L);
                 const RaySlab ur = readlaneRay(rs, L);
                 const float lim = readlaneF(tmax, L);
                 CoopTrace ct = shadowL ? coopTraceWhole<true>(s, un, ur, lim) : coopTraceWhole<false>(s, un, ur, lim);
@@ -342,7 +371,7 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
                     hitBary = ct.bary;
                     tmax = ct.tmax;
                     occluded = ct.found;
-                    node = end;
+                    node = END;
                     alive = false;
                     if (COUNT) {
                         ws.nodes += ct.nodes;
@@ -359,7 +388,7 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
             bool walking = alive && pending < 0;
             const int nStart = __popcll(__ballot(walking));
 #if RD_WF_COOP_LONE
-            if (nStart == 1) {  // a lone walker (the end of a stage): the whole wave tests 64 boxes ahead for it
+            if (!TREE && nStart == 1) {  // a lone walker (the end of a stage): the whole wave tests 64 boxes ahead for it
                 const int L = __ffsll((long long)__ballot(walking)) - 1;
                 CoopResult cr = coopWalk(readlanePtr(nodes, L), readlaneI(node, L), end, readlaneRay(rs, L), readlaneF(tmax, L), RD_COOP_WINDOWS);
                 if (int(threadIdx.x & 63u) == L) {
@@ -374,19 +403,23 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
                 const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
                 do {
                     if (walking) {
-                        float4 lo = nodes[node].lo_prim;
-                        float4 hi = nodes[node].hi_next;
-                        float boundDist;
                         if (COUNT) ws.nodes++;
-                        bool boundHit = aabbFast(lo, hi, rs, boundDist);
-                        if (boundHit && boundDist < tmax) {
-                            pending = __float_as_int(lo.w);
-                            node++;
+                        if (TREE) {
+                            treeBoxStep(s.tree, stk, int(threadIdx.x & 63u), ovf, rs, tmax, ord, node, sp, tos, pending);
                         } else {
-                            node = __float_as_int(hi.w);
+                            float4 lo = nodes[node].lo_prim;
+                            float4 hi = nodes[node].hi_next;
+                            float boundDist;
+                            bool boundHit = aabbFast(lo, hi, rs, boundDist);
+                            if (boundHit && boundDist < tmax) {
+                                pending = __float_as_int(lo.w);
+                                node++;
+                            } else {
+                                node = __float_as_int(hi.w);
+                            }
                         }
-                        walking = pending < 0 && node != end;
-                        alive = (node != end) || pending >= 0;
+                        walking = pending < 0 && node != END;
+                        alive = (node != END) || pending >= 0;
                     }
                 } while (__popcll(__ballot(walking)) >= (minWalk > 1 ? minWalk : 1));
             }
@@ -401,7 +434,7 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
             if (hit && dist < tmax) {
                 if (isShadow) {
                     occluded = true;
-                    node = end;
+                    node = END;
                 } else {
                     hitPrim = pending;
                     tmax = dist;
@@ -409,7 +442,7 @@ __global__ __launch_bounds__(256) void k_wf_trace(DScene s, WaveWorkspace w, int
                 }
             }
             pending = -1;
-            alive = node != end;
+            alive = node != END;
         }
         // ---- retire finished lanes: together, once done lanes * 64 >= (walking + done) lanes * RD_WF_FINISH_MIN (the records are
         // dependent read-modify-writes; a lane that has finished keeps its path slot in p until then and is not refilled) ----

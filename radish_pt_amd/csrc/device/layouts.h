@@ -68,8 +68,20 @@ struct Counters {
     unsigned long long closestRays, anyRays, nodeVisits, triTests, closestHits;
 };
 
+// The same tree ONCE, for the per-lane walks (round 3): record b = box of tree node b; lo_prim.w = primitiveId of a leaf, or
+// ~c for an inner node whose two children are records c and c + 1; hi_next.w = six bits, bit k set when ordering k
+// (src/bvh.cpp:171-180) visits child c + 1 first.  A walk keeps its pending far children on a small per-lane stack (LDS) instead
+// of following a per-ordering miss link, so all six orderings share 32 B per node instead of 6 x 32 B: the visiting order — near
+// child, its subtree, far child — is the threaded order of nodes[k] (pre-order, near child first), hence the same decisions
+// and the same counters.  Record numbering: the root is 0, a node's children are allocated as a pair when the node is reached in
+// ordering 0's pre-order (so sibling boxes share a 64-byte half line).  Null when the six arrays handed to rdh_scene_upload are
+// not six pre-orders of ONE binary tree (then every kernel walks nodes[k]).
+constexpr int kTreeEnd = -1;  // node value of a finished walk
+
 struct DScene {
     const NodeRec *nodes[6];  // one allocation: nodes[k] = nodes[0] + k * (bvhSize + 1)
+    const NodeRec *tree;      // bvhSize (+1 pad) records, or null
+    int treeDepth;            // most far children any walk can have pending at once (over the six orderings)
     const TriRec *tris;
     const AttrRec *attrs;
     const MatRec *mats;

@@ -48,7 +48,14 @@ struct rdh_ctx {
     unsigned persistGrid = 0;
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
+    unsigned treeGrid[2] = {0, 0};  // ... of k_walk_tree<false, false / true>
+    int *treeOvf = nullptr;         // the deep end of the tree walkers' per-lane stacks (kernels_walk.h)
+    size_t treeOvfInts = 0;
     unsigned wfGrid[4] = {0, 0, 0, 0};  // resident workgroups of k_wf_trace<false> / <true>, (unused), k_wf_shade
+    unsigned wfGridTree[2] = {0, 0};    // ... of k_wf_trace<false, true> / <true, true>
+    int *wfTreeOvf[3] = {nullptr, nullptr, nullptr};  // per sub-frame workspace: the deep end of the tree walkers' stacks
+    size_t wfTreeOvfInts[3] = {0, 0, 0};
+    int treeMode = -1;  // -1: by scene size (useTree); 0 / 1: RADISH_TREE in the environment (experiments)
     float *posPlane = nullptr;  // denoisers: Camera::getPosition of every pixel (k_position_plane)
     long long posPlanePixels = 0;
     // Longest-paths-first block order (k_persist_schedule), off the critical path: launch n writes blockCost[n & 1]; the
@@ -150,6 +157,94 @@ float asFloat(int32_t i) {
     return f;
 }
 
+// DScene::tree (layouts.h) from the reference-layout arrays: ONE record per tree node, shared by the six orderings.  Returns false
+// (no tree; the kernels then walk the six threaded arrays) unless bvhNodes[0..5] are six pre-orders of one binary tree over
+// boundingBoxes — which is what BVHBuilder::buildMTBVH emits (src/bvh.cpp:136-183) — that differ only in which child comes first.
+// The caller has range-checked every node already.  `depth` = the most far children a walk can have pending at once.
+bool buildSharedTree(const rdh_scene_desc *d, int S, std::vector<NodeRec> &tree, int &depth) {
+    if (S <= 0) return false;
+    std::vector<int> canon((size_t)S, -1);
+    tree.assign((size_t)S + 1, NodeRec{});
+    tree[S].lo_prim = make_float4(0.f, 0.f, 0.f, asFloat(0));  // pad record, never visited
+    tree[S].hi_next = make_float4(0.f, 0.f, 0.f, asFloat(0));
+    std::vector<int> w3((size_t)S, 0), bits((size_t)S, 0);
+    int nextFree = 1;
+    std::vector<unsigned char> seen((size_t)S, 0);
+    {
+        const int32_t *src = d->bvhNodes[0];
+        canon[src[1]] = 0;
+        for (int p = 0; p < S; p++) {
+            const int prim = src[3 * p], box = src[3 * p + 1], next = src[3 * p + 2];
+            const int b = canon[box];
+            if (b < 0 || seen[b]) return false;  // reached before its parent, or twice: not a pre-order
+            seen[b] = 1;
+            if (prim >= 0) {
+                if (next != p + 1) return false;
+                w3[b] = prim;
+            } else {
+                const int first = p + 1;
+                if (first >= S) return false;
+                const int second = src[3 * first + 2];
+                if (second <= first || second >= S || src[3 * second + 2] != next) return false;
+                const int bf = src[3 * first + 1], bs = src[3 * second + 1];
+                if (bf == bs || canon[bf] >= 0 || canon[bs] >= 0 || nextFree + 2 > S) return false;
+                canon[bf] = nextFree;
+                canon[bs] = nextFree + 1;
+                w3[b] = ~nextFree;
+                nextFree += 2;
+            }
+        }
+        if (nextFree != S) return false;
+    }
+    for (int k = 1; k < 6; k++) {
+        const int32_t *src = d->bvhNodes[k];
+        std::fill(seen.begin(), seen.end(), 0);
+        for (int p = 0; p < S; p++) {
+            const int prim = src[3 * p], box = src[3 * p + 1], next = src[3 * p + 2];
+            const int b = canon[box];
+            if (b < 0 || seen[b]) return false;
+            seen[b] = 1;
+            if (p == 0 && b != 0) return false;
+            if (prim >= 0) {
+                if (next != p + 1 || w3[b] != prim) return false;
+            } else {
+                if (w3[b] >= 0) return false;
+                const int first = p + 1;
+                if (first >= S) return false;
+                const int second = src[3 * first + 2];
+                if (second <= first || second >= S || src[3 * second + 2] != next) return false;
+                const int c0 = ~w3[b], cf = canon[src[3 * first + 1]], cs = canon[src[3 * second + 1]];
+                if (cf == c0 && cs == c0 + 1) {
+                } else if (cf == c0 + 1 && cs == c0) {
+                    bits[b] |= 1 << k;
+                } else {
+                    return false;
+                }
+            }
+        }
+    }
+    // pending far children on the way down, per ordering (children have larger record numbers than their parent)
+    depth = 0;
+    std::vector<int> pend((size_t)S);
+    for (int k = 0; k < 6; k++) {
+        pend[0] = 0;
+        for (int b = 0; b < S; b++) {
+            if (w3[b] >= 0) continue;
+            const int c0 = ~w3[b], nb = (bits[b] >> k) & 1;
+            pend[c0 + nb] = pend[b] + 1;
+            pend[c0 + (nb ^ 1)] = pend[b];
+            if (pend[b] + 1 > depth) depth = pend[b] + 1;
+        }
+    }
+    for (int box = 0; box < S; box++) {
+        const int b = canon[box];
+        const float *q = d->boundingBoxes + 6 * (size_t)box;
+        tree[b].lo_prim = make_float4(q[0], q[1], q[2], asFloat(w3[b]));
+        tree[b].hi_next = make_float4(q[3], q[4], q[5], asFloat(bits[b]));
+    }
+    return true;
+}
+
 struct HostCamera {  // src/sceneStructs.h:118-130
     int32_t resx, resy;
     float position[3], rotation[3], view[3], up[3], right[3];
@@ -195,6 +290,17 @@ PixelMap makePixelMap(const rdh_ctx *c) {
     int bpe = pm.tile / 8;
     pm.numBlocks = pm.tilesPerRank * bpe * bpe;
     return pm;
+}
+
+// Do the per-lane walks of this launch go over the shared tree (DScene::tree) or over the six threaded arrays?  Measured on each
+// scene's own frame rays (profiles/r03_g_*): Cornell (37 k nodes) 1.02x the time, teapots (201 k) 0.89x, 1 M triangles 0.85x — the
+// six-fold smaller footprint pays once the threaded arrays outgrow the L2s.  RDH_PT_TREE / RDH_PT_NO_TREE force it either way.
+constexpr int kTreeMinNodes = 100000;
+bool useTree(const rdh_ctx *c, uint32_t flags) {
+    if (!c->ds.tree || (flags & RDH_PT_NO_TREE)) return false;
+    if (flags & RDH_PT_TREE) return true;
+    if (c->treeMode >= 0) return c->treeMode != 0;
+    return c->ds.bvhSize >= kTreeMinNodes;
 }
 
 // Grid for "4 waves per workgroup, one 8x8 block per wave", padded to a multiple of 8 workgroups (xcdSwizzle).
@@ -292,7 +398,14 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
             unsigned g = (unsigned)((per[q] < 1 ? 1 : per[q]) * cus);
             c->wfGrid[q] = g < kPersistentGrid ? g : kPersistentGrid;
         }
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[0], (k_wf_trace<false, true>), 256, 0));
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[1], (k_wf_trace<true, true>), 256, 0));
+        for (int q = 0; q < 2; q++) {
+            unsigned g = (unsigned)((per[q] < 1 ? 1 : per[q]) * cus);
+            c->wfGridTree[q] = g < kPersistentGrid ? g : kPersistentGrid;
+        }
     }
+    const bool tree = useTree(c, flags);
     // Three sub-frames (8x8 blocks dealt round robin) as three pipelines on three streams: every stage of one pipeline ends on its
     // longest ray while the stages of the others fill the chip.  Each pipeline launches a third of the resident grid.  Measured on
     // the teapots / Cornell frame: one pipeline 12.3 / 5.14 ms, two 10.5 / 4.70, three 10.2 / 4.58, four 10.4 / 5.0.  Small frames
@@ -302,7 +415,24 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     // persistent grids: what stays resident, shared between the sub-frame pipelines and between the contexts that render side by
     // side on this GPU (rdh_set_occupancy_share)
     const unsigned div = (unsigned)parts * (unsigned)c->share;
-    const unsigned traceGrid = std::max(8u, c->wfGrid[count ? 1 : 0] / div), shadeGrid = std::max(8u, c->wfGrid[3] / div);
+    const unsigned traceGrid = std::max(8u, (tree ? c->wfGridTree[count ? 1 : 0] : c->wfGrid[count ? 1 : 0]) / div);
+    const unsigned shadeGrid = std::max(8u, c->wfGrid[3] / div);
+    if (tree) {  // the deep end of the walkers' stacks (anything that can fail comes before the fork)
+        const int ovfDepth = c->ds.treeDepth >= kTreeLds ? c->ds.treeDepth - kTreeLds + 1 : 1;
+        const size_t need = (size_t)traceGrid * 4 * 64 * (size_t)ovfDepth;
+        for (int h = 0; h < parts; h++) {
+            if (need > c->wfTreeOvfInts[h]) {
+                HIP_TRY(c, hipDeviceSynchronize());
+                if (c->wfTreeOvf[h]) hipFree(c->wfTreeOvf[h]);
+                c->wfTreeOvf[h] = nullptr;
+                c->wfTreeOvfInts[h] = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->wfTreeOvf[h], need * sizeof(int)));
+                c->wfTreeOvfInts[h] = need;
+            }
+            c->wf[h].treeOvf = c->wfTreeOvf[h];
+            c->wf[h].treeOvfDepth = ovfDepth;
+        }
+    }
     // RDH_PT_PROFILE with sub-frames: the pipelines' launches overlap by design, so what is timed is the FRAME — one event pair
     // from before the fork to after the join, on the context's stream (one pipeline: a pair around every k_wf_trace launch)
     const long pf = parts >= 2 ? profBegin(c, flags) : -1;
@@ -333,7 +463,9 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
             hipStream_t st = sts[h];
             WaveWorkspace &w = c->wf[h];
             long pe = (h == 0 && parts == 1) ? profBegin(c, flags) : -1;
-            if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(traceGrid), dim3(256), 0, st, c->ds, w, k);
+            if (tree && count) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(traceGrid), dim3(256), 0, st, c->ds, w, k);
+            else if (tree) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(traceGrid), dim3(256), 0, st, c->ds, w, k);
+            else if (count) hipLaunchKernelGGL(k_wf_trace<true>, dim3(traceGrid), dim3(256), 0, st, c->ds, w, k);
             else hipLaunchKernelGGL(k_wf_trace<false>, dim3(traceGrid), dim3(256), 0, st, c->ds, w, k);
             profEnd(c, pe);
             hipLaunchKernelGGL(k_wf_shade, dim3(shadeGrid), dim3(256), 0, st, c->ds, w, k, maxDepth, sort ? 1 : 0);
@@ -419,6 +551,47 @@ int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *
     return RDH_OK;
 }
 
+// k_walk_tree (RDH_PT_TREE): the same walk over the shared tree, DScene::tree.
+int launchWalkTree(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *d_occ, bool count) {
+    const int any = d_occ ? 1 : 0;
+    if (!c->ds.tree) return fail(c, RDH_ERR_UNSUPPORTED, "RDH_PT_TREE: the uploaded node arrays are not six orderings of one binary tree");
+    if (c->treeGrid[any] == 0) {
+        int perCU = 0, cus = 0;
+        if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_tree<false, true>), 64, 0));
+        else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_tree<false, false>), 64, 0));
+        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->treeGrid[any] = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
+    }
+    const unsigned long long chunks = (unsigned long long)((n + 63) / 64);
+    unsigned resident = c->treeGrid[any] / (unsigned)c->share;
+    if (resident < 8u) resident = 8u;
+    const unsigned grid = chunks < resident ? (unsigned)chunks : resident;
+    const int ovfDepth = c->ds.treeDepth > kTreeLds ? c->ds.treeDepth - kTreeLds + 1 : 1;
+    const size_t need = (size_t)std::max(c->treeGrid[0], c->treeGrid[1]) * 64 * (size_t)ovfDepth;
+    if (need > c->treeOvfInts) {
+        if (c->treeOvf) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            hipFree(c->treeOvf);
+            c->treeOvf = nullptr;
+            c->treeOvfInts = 0;
+        }
+        HIP_TRY(c, hipMalloc((void **)&c->treeOvf, need * sizeof(int)));
+        c->treeOvfInts = need;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
+    const int *none = nullptr;
+    if (any && count)
+        hipLaunchKernelGGL((k_walk_tree<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, c->treeOvf, ovfDepth, none, 0);
+    else if (any)
+        hipLaunchKernelGGL((k_walk_tree<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, c->treeOvf, ovfDepth, none, 0);
+    else if (count)
+        hipLaunchKernelGGL((k_walk_tree<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, c->treeOvf, ovfDepth, none, 0);
+    else
+        hipLaunchKernelGGL((k_walk_tree<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, c->treeOvf, ovfDepth, none, 0);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
 void timeBegin(rdh_ctx *c) {
     hipEventRecord(c->evStart, c->stream);
 }
@@ -463,6 +636,7 @@ int rdh_create(rdh_ctx **out, int device) {
         delete c;
         return RDH_ERR_NO_DEVICE;
     }
+    if (const char *e = getenv("RADISH_TREE")) c->treeMode = atoi(e) != 0 ? 1 : 0;  // experiments: force the shared-tree walks on / off
     *out = c;
     return RDH_OK;
 }
@@ -488,6 +662,9 @@ void rdh_destroy(rdh_ctx *c) {
     if (c->dCounters) hipFree(c->dCounters);
     if (c->dPersist) hipFree(c->dPersist);
     if (c->posPlane) hipFree(c->posPlane);
+    if (c->treeOvf) hipFree(c->treeOvf);
+    for (int h = 0; h < 3; h++)
+        if (c->wfTreeOvf[h]) hipFree(c->wfTreeOvf[h]);
     if (c->sideStream) hipStreamSynchronize(c->sideStream);
     for (int k = 0; k < 2; k++) {
         if (c->blockCost[k]) hipFree(c->blockCost[k]);
@@ -661,6 +838,16 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
     }
     if ((rc = uploadVec(c, nodes, &c->ds.nodes[0]))) return rc;
     for (int k = 1; k < 6; k++) c->ds.nodes[k] = c->ds.nodes[0] + (size_t)k * (S + 1);
+    {  // the same tree once (layouts.h, DScene::tree) — when the six arrays ARE six pre-orders of one binary tree
+        std::vector<NodeRec> tree;
+        int depth = 0;
+        c->ds.tree = nullptr;
+        c->ds.treeDepth = 0;
+        if (buildSharedTree(d, S, tree, depth)) {
+            if ((rc = uploadVec(c, tree, &c->ds.tree))) return rc;
+            c->ds.treeDepth = depth;
+        }
+    }
 
     std::vector<LightRec> lights(d->numLights);
     for (int i = 0; i < d->numLights; i++) {
@@ -1696,7 +1883,8 @@ static int walkPersistent(rdh_ctx *c, const float *d_rays, int64_t n, int4 *d_hi
         return timeEnd(c, what);
     }
     timeBegin(c);
-    int rc = launchWalk(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0);
+    int rc = ((flags & RDH_PT_TREE) || useTree(c, flags)) ? launchWalkTree(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
+                                                          : launchWalk(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0);
     if (rc) return rc;
     return timeEnd(c, what);
 }

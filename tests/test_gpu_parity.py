@@ -49,7 +49,11 @@ def cornell_gpu(gpu_ctx, cornell_small):
 # ---------------------------------------------------------------------------------------------------------------------
 # traversal
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent"])
+def _walker_flags(api, kernel):
+    return {"one_lane_per_ray": 0, "persistent": api.RDH_PT_PERSISTENT, "shared_tree": api.RDH_PT_PERSISTENT | api.RDH_PT_TREE}[kernel]
+
+
+@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent", "shared_tree"])
 def test_trace_closest_bit_exact(cornell_gpu, cornell_small, kernel):
     from radish_pt_amd import api, layouts as L
 
@@ -60,7 +64,7 @@ def test_trace_closest_bit_exact(cornell_gpu, cornell_small, kernel):
     d_rays = _dev(rays)
     d_hits = torch.zeros(len(rays), 4, dtype=torch.int32, device="cuda")
     cornell_gpu.counters_reset()
-    cornell_gpu.trace_closest(d_rays, d_hits, api.RDH_PT_COUNT | (api.RDH_PT_PERSISTENT if kernel == "persistent" else 0))
+    cornell_gpu.trace_closest(d_rays, d_hits, api.RDH_PT_COUNT | _walker_flags(api, kernel))
     got = d_hits.cpu().numpy().view(L.HIT_DTYPE).reshape(-1)
     assert np.array_equal(got["primId"], ref["primId"])
     for f in ("u", "v", "t"):
@@ -115,7 +119,7 @@ def test_nan_origin_ray_gets_a_record_in_every_walker(cornell_gpu, cornell_small
         assert ct["nodeVisits"] == st_o["nodeVisits"] and ct["triTests"] == st_o["triTests"]
 
 
-@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent"])
+@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent", "shared_tree"])
 def test_trace_occluded_exact(cornell_gpu, cornell_small, kernel):
     from radish_pt_amd import api
 
@@ -125,7 +129,7 @@ def test_trace_occluded_exact(cornell_gpu, cornell_small, kernel):
     ref = o.trace_occluded(seg)
     d_out = torch.full((len(seg),), -1, dtype=torch.int32, device="cuda")
     cornell_gpu.counters_reset()
-    cornell_gpu.trace_occluded(_dev(seg), d_out, api.RDH_PT_COUNT | (api.RDH_PT_PERSISTENT if kernel == "persistent" else 0))
+    cornell_gpu.trace_occluded(_dev(seg), d_out, api.RDH_PT_COUNT | _walker_flags(api, kernel))
     assert np.array_equal(d_out.cpu().numpy(), ref)
     assert 0.05 < ref.mean() < 0.95
     st, ct = o.stats(), cornell_gpu.counters()
