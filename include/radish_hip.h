@@ -114,6 +114,8 @@ typedef struct rdh_counters {
                                   RDH_PT_PERSISTENT) return RDH_ERR_UNSUPPORTED when the uploaded arrays are not six orderings of one
                                   binary tree; the frame entries then walk the threaded arrays */
 #define RDH_PT_NO_TREE 16384u  /* never walk the shared tree */
+#define RDH_PT_PAIRS 32768u    /* per-lane walks over SIBLING PAIRS: a lane that enters a node fetches both children (one 64-byte record)
+                                  and tests both boxes in one round trip; the far child is re-checked when the walk reaches it */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_pt_persistent, k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read.  With

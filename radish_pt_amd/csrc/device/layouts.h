@@ -78,10 +78,25 @@ struct Counters {
 // not six pre-orders of ONE binary tree (then every kernel walks nodes[k]).
 constexpr int kTreeEnd = -1;  // node value of a finished walk
 
+// The same tree as SIBLING PAIRS: record q = the two children of one inner node, 64 B on one 64-byte half line — both are visited
+// by every walk that enters the parent (the near one now, the far one when the near subtree is done), so one round trip serves
+// two visits.  w = primitiveId of a leaf child, or ~q' when the child is an inner node whose children are pair q'.  `bits` as in
+// DScene::tree: bit k set when ordering k visits child 1 first.  Pairs are numbered in ordering 0's pre-order of their parents
+// (the root's pair is 0).  The root itself — a box every walk tests first — travels in DScene (kernel arguments, no load).
+struct __attribute__((aligned(64))) PairRec {
+    float4 lo0_w0;    // child 0: pMin.xyz, w
+    float4 hi0_bits;  // child 0: pMax.xyz, the parent's ordering bits
+    float4 lo1_w1;    // child 1: pMin.xyz, w
+    float4 hi1_pad;   // child 1: pMax.xyz, 0
+};
+static_assert(sizeof(PairRec) == 64, "PairRec");
+
 struct DScene {
     const NodeRec *nodes[6];  // one allocation: nodes[k] = nodes[0] + k * (bvhSize + 1)
     const NodeRec *tree;      // bvhSize (+1 pad) records, or null
     int treeDepth;            // most far children any walk can have pending at once (over the six orderings)
+    const PairRec *pairs;     // (bvhSize - 1) / 2 records, or null (exactly when `tree` is null)
+    float4 rootLo, rootHi;    // the root's box; rootLo.w = its w (a one-triangle scene has a leaf root)
     const TriRec *tris;
     const AttrRec *attrs;
     const MatRec *mats;

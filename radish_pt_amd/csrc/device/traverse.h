@@ -659,6 +659,103 @@ RD_DEV void treeBoxStep(const NodeRec *__restrict__ tree, int *stk, int lane, in
     }
 }
 
+// ---- walks over SIBLING PAIRS (DScene::pairs, layouts.h) -----------------------------------------------------------------------
+// DevScene::intersect visits the two children of an inner node one after the other — the near one (by the ray's ordering) when it
+// enters the node, the far one when the near subtree is done — and tests each box against the closest distance of THAT moment.
+// Here a lane that enters a node fetches both children in one round trip (one 64-byte record) and tests both boxes at once:
+//   * the near child is "visited" now: a hit leaf is parked for its triangle test, a hit inner node is entered next;
+//   * the far child is visited LATER, so its test is only PROVISIONAL: tmax can but shrink until then, hence a box that fails now
+//     (missed, or boundDist >= tmax) fails then as well and nothing need be kept for it, while a box that passes is pushed as
+//     {w, boundDist} and re-checked against the tmax of the moment it is popped — exactly the reference's `boundDist < closestDist`
+//     at the reference's time.  Triangles are therefore tested in the reference's order against the reference's distances: same
+//     hits (same strict-< ties), and with COUNT the failed far children are pushed too (distance +inf) and every far child is
+//     counted when it is popped, i.e. when the sequential walk reaches it — so an any-hit walk that ends early counts what the
+//     reference counts.
+// What it buys: half the dependent round trips per visit, and stacks a few entries deep (only far children that are hit) where the
+// one-node form (treeBoxStep) needs one entry per level of these 46-102-level trees.
+// Per-lane state: `cur` = the pair to enter next (-1: none), `sp` = entries on the stack; rows 0 .. kPairLds - 1 live in LDS
+// (`stk`: this wave's [row][lane] block of int2), deeper ones in this wave's strip of global memory (`ovf`).
+#ifndef RD_PAIR_LDS
+#define RD_PAIR_LDS 8
+#endif
+constexpr int kPairLds = RD_PAIR_LDS;
+constexpr int kPairNone = -1, kPairFresh = -2;  // `cur`: nothing to enter / a literal-class ray that has not started (traced whole)
+RD_DEV void pairPush(int2 *stk, int lane, int2 *__restrict__ ovf, int &sp, int w, float d) {
+    const int2 e = make_int2(w, __float_as_int(d));
+    if (sp < kPairLds) stk[sp * 64 + lane] = e;
+    else ovf[(size_t)(sp - kPairLds) * 64 + lane] = e;
+    sp++;
+}
+RD_DEV int2 pairPop(const int2 *stk, int lane, const int2 *__restrict__ ovf, int &sp) {
+    sp--;
+    return sp < kPairLds ? stk[sp * 64 + lane] : ovf[(size_t)(sp - kPairLds) * 64 + lane];
+}
+// The root: a single box, from the kernel arguments.  Class-0 rays only.  Returns true when the walk goes on.
+template <bool COUNT>
+RD_DEV void pairStart(const DScene &s, const RaySlab &rs, float tmax, int &cur, int &pending, WalkStats &ws) {
+    cur = kPairNone;
+    pending = -1;
+    if (s.bvhSize == 0) return;
+    if (COUNT) ws.nodes++;
+    float d;
+    if (aabbFast(s.rootLo, s.rootHi, rs, d) && d < tmax) {
+        const int w = __float_as_int(s.rootLo.w);
+        if (w >= 0) pending = w;
+        else cur = ~w;
+    }
+}
+// Lanes with nothing to enter take the nearest far child that is still wanted; `busy` goes false when a lane parks on a leaf or
+// its walk is over.  Wave-level loop: call from uniform control flow.
+template <bool COUNT>
+RD_DEV void pairPops(const int2 *stk, int lane, const int2 *__restrict__ ovf, float tmax, bool &busy, int &cur, int &sp, int &pending, WalkStats &ws) {
+    bool need = busy && cur < 0;
+    while (__ballot(need) != 0ull) {
+        if (need) {
+            if (sp == 0) {
+                busy = false;
+                need = false;
+            } else {
+                const int2 e = pairPop(stk, lane, ovf, sp);
+                if (COUNT) ws.nodes++;
+                if (__int_as_float(e.y) < tmax) {
+                    need = false;
+                    if (e.x >= 0) {
+                        pending = e.x;
+                        busy = false;
+                    } else {
+                        cur = ~e.x;
+                    }
+                }
+            }
+        }
+    }
+}
+// One pair step of a lane with cur >= 0.
+template <bool COUNT>
+RD_DEV void pairStep(const PairRec *__restrict__ pairs, int2 *stk, int lane, int2 *__restrict__ ovf, const RaySlab &rs, float tmax, int ord,
+                     int &cur, int &sp, int &pending, WalkStats &ws) {
+    const char *pb = reinterpret_cast<const char *>(pairs);
+    const unsigned ofs = (unsigned)cur << 6;
+    const float4 a0 = *reinterpret_cast<const float4 *>(pb + ofs);
+    const float4 a1 = *reinterpret_cast<const float4 *>(pb + ofs + 16u);
+    const float4 b0 = *reinterpret_cast<const float4 *>(pb + ofs + 32u);
+    const float4 b1 = *reinterpret_cast<const float4 *>(pb + ofs + 48u);
+    float d0, d1;
+    const bool h0 = aabbFast(a0, a1, rs, d0) && d0 < tmax;
+    const bool h1 = aabbFast(b0, b1, rs, d1) && d1 < tmax;
+    const bool second = ((__float_as_int(a1.w) >> ord) & 1) != 0;  // this ordering visits child 1 first
+    const int wN = __float_as_int(second ? b0.w : a0.w), wF = __float_as_int(second ? a0.w : b0.w);
+    const bool hN = second ? h1 : h0, hF = second ? h0 : h1;
+    const float dF = second ? d0 : d1;
+    if (COUNT) ws.nodes++;  // the near child, now; the far one when it is popped
+    if (hF || COUNT) pairPush(stk, lane, ovf, sp, wF, hF ? dF : __builtin_inff());
+    cur = kPairNone;
+    if (hN) {
+        if (wN >= 0) pending = wN;
+        else cur = ~wN;
+    }
+}
+
 // Wave-level reduction of the per-lane walk statistics, then one atomic per counter per wave.
 RD_DEV unsigned long long waveSum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -49,6 +49,7 @@ struct rdh_ctx {
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
     unsigned treeGrid[2] = {0, 0};  // ... of k_walk_tree<false, false / true>
+    unsigned pairGrid[2] = {0, 0};  // ... of k_walk_pair<false, false / true>
     int *treeOvf = nullptr;         // the deep end of the tree walkers' per-lane stacks (kernels_walk.h)
     size_t treeOvfInts = 0;
     unsigned wfGrid[4] = {0, 0, 0, 0};  // resident workgroups of k_wf_trace<false> / <true>, (unused), k_wf_shade
@@ -161,7 +162,7 @@ float asFloat(int32_t i) {
 // (no tree; the kernels then walk the six threaded arrays) unless bvhNodes[0..5] are six pre-orders of one binary tree over
 // boundingBoxes — which is what BVHBuilder::buildMTBVH emits (src/bvh.cpp:136-183) — that differ only in which child comes first.
 // The caller has range-checked every node already.  `depth` = the most far children a walk can have pending at once.
-bool buildSharedTree(const rdh_scene_desc *d, int S, std::vector<NodeRec> &tree, int &depth) {
+bool buildSharedTree(const rdh_scene_desc *d, int S, std::vector<NodeRec> &tree, std::vector<PairRec> &pairs, int &depth) {
     if (S <= 0) return false;
     std::vector<int> canon((size_t)S, -1);
     tree.assign((size_t)S + 1, NodeRec{});
@@ -241,6 +242,18 @@ bool buildSharedTree(const rdh_scene_desc *d, int S, std::vector<NodeRec> &tree,
         const float *q = d->boundingBoxes + 6 * (size_t)box;
         tree[b].lo_prim = make_float4(q[0], q[1], q[2], asFloat(w3[b]));
         tree[b].hi_next = make_float4(q[3], q[4], q[5], asFloat(bits[b]));
+    }
+    // sibling pairs (layouts.h, PairRec): children c0 = 2q + 1 and c0 + 1 of the inner node that was the (q + 1)-th to be reached
+    pairs.assign((size_t)(S - 1) / 2 + 1, PairRec{});  // + a pad record
+    auto childW = [&](int b) { return w3[b] >= 0 ? w3[b] : ~((~w3[b] - 1) / 2); };
+    for (int b = 0; b < S; b++) {
+        if (w3[b] >= 0) continue;
+        const int c0 = ~w3[b], q = (c0 - 1) / 2;
+        const float4 l0 = tree[c0].lo_prim, h0 = tree[c0].hi_next, l1 = tree[c0 + 1].lo_prim, h1 = tree[c0 + 1].hi_next;
+        pairs[q].lo0_w0 = make_float4(l0.x, l0.y, l0.z, asFloat(childW(c0)));
+        pairs[q].hi0_bits = make_float4(h0.x, h0.y, h0.z, asFloat(bits[b]));
+        pairs[q].lo1_w1 = make_float4(l1.x, l1.y, l1.z, asFloat(childW(c0 + 1)));
+        pairs[q].hi1_pad = make_float4(h1.x, h1.y, h1.z, asFloat(0));
     }
     return true;
 }
@@ -592,6 +605,48 @@ int launchWalkTree(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, i
     return RDH_OK;
 }
 
+// k_walk_pair (RDH_PT_PAIRS): the same walk over the sibling pairs, DScene::pairs.
+int launchWalkPair(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *d_occ, bool count) {
+    const int any = d_occ ? 1 : 0;
+    if (!c->ds.pairs) return fail(c, RDH_ERR_UNSUPPORTED, "RDH_PT_PAIRS: the uploaded node arrays are not six orderings of one binary tree");
+    if (c->pairGrid[any] == 0) {
+        int perCU = 0, cus = 0;
+        if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_pair<false, true>), 64, 0));
+        else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_pair<false, false>), 64, 0));
+        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->pairGrid[any] = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
+    }
+    const unsigned long long chunks = (unsigned long long)((n + 63) / 64);
+    unsigned resident = c->pairGrid[any] / (unsigned)c->share;
+    if (resident < 8u) resident = 8u;
+    const unsigned grid = chunks < resident ? (unsigned)chunks : resident;
+    const int ovfDepth = c->ds.treeDepth >= kPairLds ? c->ds.treeDepth - kPairLds + 1 : 1;
+    const size_t need = (size_t)std::max(c->pairGrid[0], c->pairGrid[1]) * 64 * (size_t)ovfDepth * 2;
+    if (need > c->treeOvfInts) {
+        if (c->treeOvf) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            hipFree(c->treeOvf);
+            c->treeOvf = nullptr;
+            c->treeOvfInts = 0;
+        }
+        HIP_TRY(c, hipMalloc((void **)&c->treeOvf, need * sizeof(int)));
+        c->treeOvfInts = need;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
+    const int *none = nullptr;
+    int2 *ovf = reinterpret_cast<int2 *>(c->treeOvf);
+    if (any && count)
+        hipLaunchKernelGGL((k_walk_pair<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, ovf, ovfDepth, none, 0);
+    else if (any)
+        hipLaunchKernelGGL((k_walk_pair<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, ovf, ovfDepth, none, 0);
+    else if (count)
+        hipLaunchKernelGGL((k_walk_pair<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, ovf, ovfDepth, none, 0);
+    else
+        hipLaunchKernelGGL((k_walk_pair<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, ovf, ovfDepth, none, 0);
+    HIP_TRY(c, hipGetLastError());
+    return RDH_OK;
+}
+
 void timeBegin(rdh_ctx *c) {
     hipEventRecord(c->evStart, c->stream);
 }
@@ -840,12 +895,18 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
     for (int k = 1; k < 6; k++) c->ds.nodes[k] = c->ds.nodes[0] + (size_t)k * (S + 1);
     {  // the same tree once (layouts.h, DScene::tree) — when the six arrays ARE six pre-orders of one binary tree
         std::vector<NodeRec> tree;
+        std::vector<PairRec> pairs;
         int depth = 0;
         c->ds.tree = nullptr;
+        c->ds.pairs = nullptr;
         c->ds.treeDepth = 0;
-        if (buildSharedTree(d, S, tree, depth)) {
+        if (buildSharedTree(d, S, tree, pairs, depth)) {
             if ((rc = uploadVec(c, tree, &c->ds.tree))) return rc;
+            if ((rc = uploadVec(c, pairs, &c->ds.pairs))) return rc;
             c->ds.treeDepth = depth;
+            c->ds.rootLo = make_float4(tree[0].lo_prim.x, tree[0].lo_prim.y, tree[0].lo_prim.z,
+                                       asFloat(__builtin_bit_cast(int, tree[0].lo_prim.w) >= 0 ? __builtin_bit_cast(int, tree[0].lo_prim.w) : ~0));
+            c->ds.rootHi = tree[0].hi_next;
         }
     }
 
@@ -1883,8 +1944,9 @@ static int walkPersistent(rdh_ctx *c, const float *d_rays, int64_t n, int4 *d_hi
         return timeEnd(c, what);
     }
     timeBegin(c);
-    int rc = ((flags & RDH_PT_TREE) || useTree(c, flags)) ? launchWalkTree(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
-                                                          : launchWalk(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0);
+    int rc = (flags & RDH_PT_PAIRS)                         ? launchWalkPair(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
+             : ((flags & RDH_PT_TREE) || useTree(c, flags)) ? launchWalkTree(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
+                                                            : launchWalk(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0);
     if (rc) return rc;
     return timeEnd(c, what);
 }

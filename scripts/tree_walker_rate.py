@@ -20,7 +20,8 @@ for name in names:
     closest, segs = ctx.dump_rays(3, 8)
     nC, nA = closest.shape[0], segs.shape[0]
     res = {}
-    for label, fl in (("threaded", api.RDH_PT_PERSISTENT), ("tree", api.RDH_PT_PERSISTENT | api.RDH_PT_TREE)):
+    for label, fl in (("threaded", api.RDH_PT_PERSISTENT | api.RDH_PT_NO_TREE), ("tree", api.RDH_PT_PERSISTENT | api.RDH_PT_TREE),
+                      ("pairs", api.RDH_PT_PERSISTENT | api.RDH_PT_PAIRS)):
         hits = torch.zeros(nC, 4, dtype=torch.int32, device="cuda")
         occ = torch.zeros(max(nA, 1), dtype=torch.int32, device="cuda")
         ctx.counters_reset()
@@ -39,7 +40,10 @@ for name in names:
         res[label] = (hits.clone(), occ.clone(), c, ta, tb)
         print(f"{name} {W}x{H} [{label}]: closest {nC} rays {ta:.3f} ms, any {nA} segs {tb:.3f} ms, total {ta + tb:.3f} ms -> "
               f"{c['nodeVisits'] / ((ta + tb) * 1e-3) / 1e9:.1f} G box steps/s, {(nC + nA) / ((ta + tb) * 1e-3) / 1e6:.0f} Mrays/s", flush=True)
-    a, b = res["threaded"], res["tree"]
-    same = bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2])
-    print(f"{name}: records and counters equal: {same}; tree / threaded time = {(b[3] + b[4]) / (a[3] + a[4]):.3f}", flush=True)
+    a = res["threaded"]
+    for k in ("tree", "pairs"):
+        b = res[k]
+        same = bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2])
+        print(f"{name}: {k}: records and counters equal: {same}; {k} / threaded time = {(b[3] + b[4]) / (a[3] + a[4]):.3f} "
+              f"(closest {b[3] / a[3]:.3f}, any {b[4] / a[4]:.3f})", flush=True)
     ctx.close()
