@@ -427,7 +427,8 @@ __global__ __launch_bounds__(64) void k_walk_pair(DScene s, const float *__restr
     rs.o = rs.d = rs.inv = mk3(0.f);
     rs.cls = 0;
     int ord = 0;
-    int cur = kPairNone, pending = -1, sp = 0;
+    int cur = kPairNone, pending = -1;
+    PairStack sp{0, 0};
     float tmax = 0.f;
     int hitPrim = -1;
     v2 hitBary = mk2(0.f, 0.f);
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(64) void k_walk_pair(DScene s, const float *__restr
                         }
                         rs = makeRaySlab(ray);
                         ord = getMTBVHId(-ray.d);
-                        sp = 0;
+                        sp = PairStack{0, 0};
                         hitPrim = -1;
                         hitBary = mk2(0.f, 0.f);
                         found = false;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(64) void k_walk_pair(DScene s, const float *__restr
         }
         // ---------------- box steps ----------------
         {
-            bool busy = state == W_TRACE && pending < 0 && (cur >= 0 || sp > 0);
+            bool busy = state == W_TRACE && pending < 0 && (cur >= 0 || sp.sp > 0);
             const int nStart = __popcll(__ballot(busy));
             if (nStart > 0) {
                 const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(64) void k_walk_pair(DScene s, const float *__restr
                     pairPops<COUNT>(stk, lane, ovf, tmax, busy, cur, sp, pending, ws);
                     if (busy) {  // cur >= 0
                         pairStep<COUNT>(s.pairs, stk, lane, ovf, rs, tmax, ord, cur, sp, pending, ws);
-                        busy = pending < 0 && (cur >= 0 || sp > 0);
+                        busy = pending < 0 && (cur >= 0 || sp.sp > 0);
                     }
                 } while (__popcll(__ballot(busy)) >= (minWalk > 1 ? minWalk : 1));
             }
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(64) void k_walk_pair(DScene s, const float *__restr
                 if (ANY) {
                     found = true;
                     cur = kPairNone;
-                    sp = 0;
+                    sp = PairStack{0, 0};
                 } else {
                     hitPrim = pending;
                     tmax = dist;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(64) void k_walk_pair(DScene s, const float *__restr
             }
             pending = -1;
         }
-        if (state == W_TRACE && pending < 0 && cur == kPairNone && sp == 0) state = W_DONE;
+        if (state == W_TRACE && pending < 0 && cur == kPairNone && sp.sp == 0) state = W_DONE;
         // ---------------- records of finished rays ----------------
         {
             const unsigned long long doneM = __ballot(state == W_DONE);

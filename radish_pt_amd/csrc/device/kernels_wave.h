@@ -158,15 +158,15 @@ __global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelM
 #define RD_WF_COOP_LONE 1
 #endif
 
-// TREE: the per-lane walks go over the shared tree (DScene::tree: one 32-byte record per node for all six orderings, pending far
-// children on a per-lane stack in LDS; traverse.h, treeBoxStep) instead of the six threaded arrays — same visits in the same order.
-// Chosen by the host for big scenes (radish_hip.hip, useTree): closest-hit walks of mixed directions gain ~20 % from the six-fold
-// smaller node footprint, the shadow walks (one direction class, so one threaded array anyway) pay ~5 % for the stack.
-#ifndef RD_WF_TREE_WAVES
-#define RD_WF_TREE_WAVES 7  // waves per SIMD the tree variant is held to (its 79 VGPRs would leave 6)
+// PAIRS: the per-lane walks go over the sibling pairs (DScene::pairs: ONE 64-byte record per inner node for all six orderings, both
+// children fetched and tested per round trip, the far one re-checked when the walk reaches it; traverse.h, pairStep) instead of the
+// six threaded arrays — same triangle tests in the same order, same counters.  Chosen by the host for big scenes (radish_hip.hip,
+// usePairs): a sixth of the node footprint and half the dependent round trips (profiles/r03_h_*).
+#ifndef RD_WF_PAIR_WAVES
+#define RD_WF_PAIR_WAVES 1  // waves per SIMD the pair variant is held to (1: whatever its registers allow)
 #endif
-template <bool COUNT, bool TREE = false>
-__global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_wf_trace(DScene s, WaveWorkspace w, int k) {
+template <bool COUNT, bool PAIRS = false>
+__global__ __launch_bounds__(256, PAIRS && !COUNT ? RD_WF_PAIR_WAVES : 1) void k_wf_trace(DScene s, WaveWorkspace w, int k) {
     WaveCounters *c = w.ctr;
     const int nShadow = (k > 0) ? c->shadowCount[k - 1].v : 0;
     const int nRay = c->rayCount[k].v;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
     WalkStats ws{0, 0};
     unsigned nClosest = 0, nAny = 0, nHits = 0;
     const int end = s.bvhSize;
-    const int END = TREE ? kTreeEnd : end;  // `node` of a finished walk
+    const int END = end;  // `node` of a finished walk (!PAIRS)
 
     // wave-uniform reservation of work items; the first one is static (see wavePull)
     int resNext = globalWave() * kPacket, resEnd = resNext + kPacket;
@@ -189,8 +189,9 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
     RaySlab rs;
     rs.o = rs.d = rs.inv = mk3(0.f);
     rs.cls = 0;
-    const NodeRec *nodes = s.nodes[0];  // !TREE: the ray's threaded array
-    int ord = 0, sp = 1, tos = kTreeEnd;  // TREE: the ray's ordering, its stack (treeBoxStep)
+    const NodeRec *nodes = s.nodes[0];  // !PAIRS: the ray's threaded array
+    int ord = 0, cur = kPairNone;  // PAIRS: the ray's ordering, the pair it enters next, its stack (pairStep)
+    PairStack sp{0, 0};
     int node = END, pending = -1;
     float tmax = 0.f;
     int hitPrim = -1;
@@ -204,15 +205,15 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
     // resolve of wg_trace.h instead of 64 with a scalar one (coopTraceWhole): entry `it` of the list belongs to workgroup it % grid.
     // The list is a HINT (shade classifies by the direction it emits, this kernel by the ray it builds): an entry whose ray turns out
     // ordinary is left to a lane of the workgroup (first round below), as before.
-    // (TREE: the four waves' stack rows take over the workgroup trace's LDS once the list is done)
-    constexpr int kStackInts = TREE ? 4 * kTreeLds * 64 : 1;
+    // (PAIRS: the four waves' stack rows take over the workgroup trace's LDS once the list is done)
+    constexpr int kStackEntries = PAIRS ? 4 * kPairLds * 64 : 1;
     __shared__ union WfTraceLds {
         WgTraceSharedT<256> wg;
-        int stack[kStackInts];
+        int2 stack[kStackEntries];
     } lds;
     WgTraceSharedT<256> &wgsh = lds.wg;
-    int *const stk = lds.stack + (TREE ? int(threadIdx.x >> 6) * kTreeLds * 64 : 0);
-    int *const ovf = TREE ? w.treeOvf + (size_t)globalWave() * (size_t)w.treeOvfDepth * 64 : nullptr;
+    int2 *const stk = lds.stack + (PAIRS ? int(threadIdx.x >> 6) * kPairLds * 64 : 0);
+    int2 *const ovf = PAIRS ? reinterpret_cast<int2 *>(w.treeOvf) + (size_t)globalWave() * (size_t)w.treeOvfDepth * 64 : nullptr;
     const int nLit = c->litCount[k].v < w.litCap ? c->litCount[k].v : w.litCap;
     for (int it = int(blockIdx.x); it < nLit; it += int(gridDim.x)) {  // uniform over the workgroup
         const int e = w.litq[k & 1][it];
@@ -259,10 +260,7 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
             }
         }
     }
-    if (TREE) {
-        __syncthreads();  // every wave is done with the workgroup trace's LDS
-        stk[threadIdx.x & 63u] = kTreeEnd;  // row 0: what a walk pops last
-    }
+    if (PAIRS) __syncthreads();  // every wave is done with the workgroup trace's LDS
     bool firstRound = true;
     bool fromList = false;  // this lane's item of the first round came from the list: skip it if the workgroup has traced it above
     for (;;) {
@@ -329,18 +327,20 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
             }
             if (p >= 0) {
                 rs = makeRaySlab(ray);
-                if (TREE) {
+                pending = -1;
+                if (PAIRS) {
                     ord = getMTBVHId(-ray.d);
-                    sp = 1;
-                    tos = kTreeEnd;
+                    sp = PairStack{0, 0};
+                    if (rs.cls == 0 || end == 0) pairStart<COUNT>(s, rs, tmax, cur, pending, ws);  // the root's box
+                    else cur = kPairFresh;  // a literal-class ray: traced whole below
+                    alive = true;  // also when the root's box is missed: the lane goes through the loop once and is retired below
                 } else {
                     nodes = s.nodes[getMTBVHId(-ray.d)];
+                    node = 0;
+                    alive = node != END;
                 }
-                node = end != 0 ? 0 : END;
-                pending = -1;
                 hitPrim = -1;
                 occluded = false;
-                alive = node != END;
                 if (fromList && rs.cls != 0 && end != 0) {  // traced (and counted, and retired) by the workgroup above
                     if (isShadow) nAny--;
                     else nClosest--;
@@ -357,12 +357,12 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
 
         // ---- literal-class rays: traced whole by the whole wave (traverse.h, coopTraceWhole) ----
         {
-            unsigned long long lit = __ballot(alive && rs.cls != 0 && node == 0 && pending < 0 && (!TREE || (sp == 1 && tos == kTreeEnd)));
+            unsigned long long lit = __ballot(PAIRS ? (alive && cur == kPairFresh) : (alive && rs.cls != 0 && node == 0 && pending < 0));
             while (lit) {
                 const int L = __ffsll((long long)lit) - 1;
                 lit &= lit - 1ull;
                 const bool shadowL = readlaneI(isShadow ? 1 : 0, L) != 0;
-                const NodeRec *un = TREE ? s.nodes[0] + (size_t)readlaneI(ord, L) * (size_t)(end + 1) : readlanePtr(nodes, L);
+                const NodeRec *un = PAIRS ? s.nodes[0] + (size_t)readlaneI(ord, L) * (size_t)(end + 1) : readlanePtr(nodes, L);
                 const RaySlab ur = readlaneRay(rs, L);
                 const float lim = readlaneF(tmax, L);
                 CoopTrace ct = shadowL ? coopTraceWhole<true>(s, un, ur, lim) : coopTraceWhole<false>(s, un, ur, lim);
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
                     tmax = ct.tmax;
                     occluded = ct.found;
                     node = END;
+                    cur = kPairNone;
                     alive = false;
                     if (COUNT) {
                         ws.nodes += ct.nodes;
@@ -384,11 +385,27 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
         // one ballot + popcount per step, as in k_walk_persistent; every walker here is of class 0 (the others were traced whole).
         // (Until the end of round 2 this loop took two ballots per step, tested "enough lanes alive" as well and went through the
         // class dispatch of boxTest: the teapots frame 10.0 -> 9.3 ms, the Cornell frame 4.6 -> 4.0 ms with three sub-frames.) ----
+        if (PAIRS) {
+            bool busy = alive && pending < 0;  // cur >= 0 or entries on the stack
+            const int nStart = __popcll(__ballot(busy));
+            if (nStart > 0) {
+                const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
+                const int lane = int(threadIdx.x & 63u);
+                do {
+                    pairPops<COUNT>(stk, lane, ovf, tmax, busy, cur, sp, pending, ws);
+                    if (busy) {
+                        pairStep<COUNT>(s.pairs, stk, lane, ovf, rs, tmax, ord, cur, sp, pending, ws);
+                        busy = pending < 0 && (cur >= 0 || sp.sp > 0);
+                    }
+                } while (__popcll(__ballot(busy)) >= (minWalk > 1 ? minWalk : 1));
+                alive = alive && (pending >= 0 || cur >= 0 || sp.sp > 0);
+            }
+        } else
         {
             bool walking = alive && pending < 0;
             const int nStart = __popcll(__ballot(walking));
 #if RD_WF_COOP_LONE
-            if (!TREE && nStart == 1) {  // a lone walker (the end of a stage): the whole wave tests 64 boxes ahead for it
+            if (nStart == 1) {  // a lone walker (the end of a stage): the whole wave tests 64 boxes ahead for it
                 const int L = __ffsll((long long)__ballot(walking)) - 1;
                 CoopResult cr = coopWalk(readlanePtr(nodes, L), readlaneI(node, L), end, readlaneRay(rs, L), readlaneF(tmax, L), RD_COOP_WINDOWS);
                 if (int(threadIdx.x & 63u) == L) {
@@ -404,19 +421,15 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
                 do {
                     if (walking) {
                         if (COUNT) ws.nodes++;
-                        if (TREE) {
-                            treeBoxStep(s.tree, stk, int(threadIdx.x & 63u), ovf, rs, tmax, ord, node, sp, tos, pending);
+                        float4 lo = nodes[node].lo_prim;
+                        float4 hi = nodes[node].hi_next;
+                        float boundDist;
+                        bool boundHit = aabbFast(lo, hi, rs, boundDist);
+                        if (boundHit && boundDist < tmax) {
+                            pending = __float_as_int(lo.w);
+                            node++;
                         } else {
-                            float4 lo = nodes[node].lo_prim;
-                            float4 hi = nodes[node].hi_next;
-                            float boundDist;
-                            bool boundHit = aabbFast(lo, hi, rs, boundDist);
-                            if (boundHit && boundDist < tmax) {
-                                pending = __float_as_int(lo.w);
-                                node++;
-                            } else {
-                                node = __float_as_int(hi.w);
-                            }
+                            node = __float_as_int(hi.w);
                         }
                         walking = pending < 0 && node != END;
                         alive = (node != END) || pending >= 0;
@@ -435,6 +448,8 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
                 if (isShadow) {
                     occluded = true;
                     node = END;
+                    cur = kPairNone;
+                    sp = PairStack{0, 0};
                 } else {
                     hitPrim = pending;
                     tmax = dist;
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(256, TREE && !COUNT ? RD_WF_TREE_WAVES : 1) void k_
                 }
             }
             pending = -1;
-            alive = node != END;
+            alive = PAIRS ? (cur >= 0 || sp.sp > 0) : (node != END);
         }
         // ---- retire finished lanes: together, once done lanes * 64 >= (walking + done) lanes * RD_WF_FINISH_MIN (the records are
         // dependent read-modify-writes; a lane that has finished keeps its path slot in p until then and is not refilled) ----

@@ -673,22 +673,37 @@ RD_DEV void treeBoxStep(const NodeRec *__restrict__ tree, int *stk, int lane, in
 //     reference counts.
 // What it buys: half the dependent round trips per visit, and stacks a few entries deep (only far children that are hit) where the
 // one-node form (treeBoxStep) needs one entry per level of these 46-102-level trees.
-// Per-lane state: `cur` = the pair to enter next (-1: none), `sp` = entries on the stack; rows 0 .. kPairLds - 1 live in LDS
-// (`stk`: this wave's [row][lane] block of int2), deeper ones in this wave's strip of global memory (`ovf`).
+// Per-lane state: `cur` = the pair to enter next (-1: none) and the stack {sp, lo}: entries lo .. sp - 1 — the most recent, at
+// most kPairLds of them — live in LDS (`stk`: this wave's [slot][lane] block of int2, a ring indexed by entry number mod kPairLds),
+// entries 0 .. lo - 1 have been moved to this wave's strip of global memory (`ovf`: [entry][lane]).  A push that finds the ring
+// full moves the OLDEST resident entry out (one LDS read + one global store, nothing waits for it); a pop that finds the ring
+// empty takes the entry back from global memory.  So a walk that stays deep for a long time keeps working at the top of its
+// stack in LDS, and global traffic is paid for net crossings of the boundary only (the first version put everything above row
+// kPairLds in global memory: every step of a deep walk went there, and 6 / 8 / 12 rows measured 9.39 / 8.95 / 8.77 ms per frame).
 #ifndef RD_PAIR_LDS
-#define RD_PAIR_LDS 8
+#define RD_PAIR_LDS 8  // a power of two
 #endif
 constexpr int kPairLds = RD_PAIR_LDS;
+static_assert((kPairLds & (kPairLds - 1)) == 0, "RD_PAIR_LDS");
 constexpr int kPairNone = -1, kPairFresh = -2;  // `cur`: nothing to enter / a literal-class ray that has not started (traced whole)
-RD_DEV void pairPush(int2 *stk, int lane, int2 *__restrict__ ovf, int &sp, int w, float d) {
-    const int2 e = make_int2(w, __float_as_int(d));
-    if (sp < kPairLds) stk[sp * 64 + lane] = e;
-    else ovf[(size_t)(sp - kPairLds) * 64 + lane] = e;
-    sp++;
+struct PairStack {
+    int sp, lo;  // entries on the stack; how many of them (the oldest) are in global memory
+};
+RD_DEV void pairPush(int2 *stk, int lane, int2 *__restrict__ ovf, PairStack &st, int w, float d) {
+    if (st.sp - st.lo == kPairLds) {  // rare
+        ovf[(size_t)st.lo * 64 + lane] = stk[(st.lo & (kPairLds - 1)) * 64 + lane];
+        st.lo++;
+    }
+    stk[(st.sp & (kPairLds - 1)) * 64 + lane] = make_int2(w, __float_as_int(d));
+    st.sp++;
 }
-RD_DEV int2 pairPop(const int2 *stk, int lane, const int2 *__restrict__ ovf, int &sp) {
-    sp--;
-    return sp < kPairLds ? stk[sp * 64 + lane] : ovf[(size_t)(sp - kPairLds) * 64 + lane];
+RD_DEV int2 pairPop(const int2 *stk, int lane, const int2 *__restrict__ ovf, PairStack &st) {
+    st.sp--;
+    if (st.sp < st.lo) {  // rare
+        st.lo = st.sp;
+        return ovf[(size_t)st.sp * 64 + lane];
+    }
+    return stk[(st.sp & (kPairLds - 1)) * 64 + lane];
 }
 // The root: a single box, from the kernel arguments.  Class-0 rays only.  Returns true when the walk goes on.
 template <bool COUNT>
@@ -707,11 +722,11 @@ RD_DEV void pairStart(const DScene &s, const RaySlab &rs, float tmax, int &cur, 
 // Lanes with nothing to enter take the nearest far child that is still wanted; `busy` goes false when a lane parks on a leaf or
 // its walk is over.  Wave-level loop: call from uniform control flow.
 template <bool COUNT>
-RD_DEV void pairPops(const int2 *stk, int lane, const int2 *__restrict__ ovf, float tmax, bool &busy, int &cur, int &sp, int &pending, WalkStats &ws) {
+RD_DEV void pairPops(const int2 *stk, int lane, const int2 *__restrict__ ovf, float tmax, bool &busy, int &cur, PairStack &sp, int &pending, WalkStats &ws) {
     bool need = busy && cur < 0;
     while (__ballot(need) != 0ull) {
         if (need) {
-            if (sp == 0) {
+            if (sp.sp == 0) {
                 busy = false;
                 need = false;
             } else {
@@ -733,7 +748,7 @@ RD_DEV void pairPops(const int2 *stk, int lane, const int2 *__restrict__ ovf, fl
 // One pair step of a lane with cur >= 0.
 template <bool COUNT>
 RD_DEV void pairStep(const PairRec *__restrict__ pairs, int2 *stk, int lane, int2 *__restrict__ ovf, const RaySlab &rs, float tmax, int ord,
-                     int &cur, int &sp, int &pending, WalkStats &ws) {
+                     int &cur, PairStack &sp, int &pending, WalkStats &ws) {
     const char *pb = reinterpret_cast<const char *>(pairs);
     const unsigned ofs = (unsigned)cur << 6;
     const float4 a0 = *reinterpret_cast<const float4 *>(pb + ofs);

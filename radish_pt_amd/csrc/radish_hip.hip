@@ -53,10 +53,10 @@ struct rdh_ctx {
     int *treeOvf = nullptr;         // the deep end of the tree walkers' per-lane stacks (kernels_walk.h)
     size_t treeOvfInts = 0;
     unsigned wfGrid[4] = {0, 0, 0, 0};  // resident workgroups of k_wf_trace<false> / <true>, (unused), k_wf_shade
-    unsigned wfGridTree[2] = {0, 0};    // ... of k_wf_trace<false, true> / <true, true>
-    int *wfTreeOvf[3] = {nullptr, nullptr, nullptr};  // per sub-frame workspace: the deep end of the tree walkers' stacks
+    unsigned wfGridPair[2] = {0, 0};    // ... of k_wf_trace<false, true> / <true, true>
+    int *wfTreeOvf[3] = {nullptr, nullptr, nullptr};  // per sub-frame workspace: the deep end of the pair walkers' stacks
     size_t wfTreeOvfInts[3] = {0, 0, 0};
-    int treeMode = -1;  // -1: by scene size (useTree); 0 / 1: RADISH_TREE in the environment (experiments)
+    int pairMode = -1;  // -1: by scene size (usePairs); 0 / 1: RADISH_PAIRS in the environment (experiments)
     float *posPlane = nullptr;  // denoisers: Camera::getPosition of every pixel (k_position_plane)
     long long posPlanePixels = 0;
     // Longest-paths-first block order (k_persist_schedule), off the critical path: launch n writes blockCost[n & 1]; the
@@ -305,15 +305,16 @@ PixelMap makePixelMap(const rdh_ctx *c) {
     return pm;
 }
 
-// Do the per-lane walks of this launch go over the shared tree (DScene::tree) or over the six threaded arrays?  Measured on each
-// scene's own frame rays (profiles/r03_g_*): Cornell (37 k nodes) 1.02x the time, teapots (201 k) 0.89x, 1 M triangles 0.85x — the
-// six-fold smaller footprint pays once the threaded arrays outgrow the L2s.  RDH_PT_TREE / RDH_PT_NO_TREE force it either way.
-constexpr int kTreeMinNodes = 100000;
-bool useTree(const rdh_ctx *c, uint32_t flags) {
-    if (!c->ds.tree || (flags & RDH_PT_NO_TREE)) return false;
-    if (flags & RDH_PT_TREE) return true;
-    if (c->treeMode >= 0) return c->treeMode != 0;
-    return c->ds.bvhSize >= kTreeMinNodes;
+// Do the per-lane walks of this launch go over the sibling pairs (DScene::pairs) or over the six threaded arrays?  Measured on each
+// scene's own frame rays (profiles/r03_h_*): Cornell (37 k nodes) 1.01x the time, teapots (201 k) 0.85x, 1 M triangles 0.67x — a
+// sixth of the footprint and half the round trips pay once the threaded arrays outgrow the L2s.  RDH_PT_PAIRS / RDH_PT_NO_TREE
+// force it either way.
+constexpr int kPairMinNodes = 100000;
+bool usePairs(const rdh_ctx *c, uint32_t flags) {
+    if (!c->ds.pairs || (flags & RDH_PT_NO_TREE)) return false;
+    if (flags & RDH_PT_PAIRS) return true;
+    if (c->pairMode >= 0) return c->pairMode != 0;
+    return c->ds.bvhSize >= kPairMinNodes;
 }
 
 // Grid for "4 waves per workgroup, one 8x8 block per wave", padded to a multiple of 8 workgroups (xcdSwizzle).
@@ -415,10 +416,10 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
         HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per[1], (k_wf_trace<true, true>), 256, 0));
         for (int q = 0; q < 2; q++) {
             unsigned g = (unsigned)((per[q] < 1 ? 1 : per[q]) * cus);
-            c->wfGridTree[q] = g < kPersistentGrid ? g : kPersistentGrid;
+            c->wfGridPair[q] = g < kPersistentGrid ? g : kPersistentGrid;
         }
     }
-    const bool tree = useTree(c, flags);
+    const bool tree = usePairs(c, flags);
     // Three sub-frames (8x8 blocks dealt round robin) as three pipelines on three streams: every stage of one pipeline ends on its
     // longest ray while the stages of the others fill the chip.  Each pipeline launches a third of the resident grid.  Measured on
     // the teapots / Cornell frame: one pipeline 12.3 / 5.14 ms, two 10.5 / 4.70, three 10.2 / 4.58, four 10.4 / 5.0.  Small frames
@@ -428,11 +429,11 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     // persistent grids: what stays resident, shared between the sub-frame pipelines and between the contexts that render side by
     // side on this GPU (rdh_set_occupancy_share)
     const unsigned div = (unsigned)parts * (unsigned)c->share;
-    const unsigned traceGrid = std::max(8u, (tree ? c->wfGridTree[count ? 1 : 0] : c->wfGrid[count ? 1 : 0]) / div);
+    const unsigned traceGrid = std::max(8u, (tree ? c->wfGridPair[count ? 1 : 0] : c->wfGrid[count ? 1 : 0]) / div);
     const unsigned shadeGrid = std::max(8u, c->wfGrid[3] / div);
     if (tree) {  // the deep end of the walkers' stacks (anything that can fail comes before the fork)
-        const int ovfDepth = c->ds.treeDepth >= kTreeLds ? c->ds.treeDepth - kTreeLds + 1 : 1;
-        const size_t need = (size_t)traceGrid * 4 * 64 * (size_t)ovfDepth;
+        const int ovfDepth = c->ds.treeDepth + 1;  // entry numbers, not rows beyond the ring (traverse.h, pairPush)
+        const size_t need = (size_t)traceGrid * 4 * 64 * (size_t)ovfDepth * 2;  // int2 entries
         for (int h = 0; h < parts; h++) {
             if (need > c->wfTreeOvfInts[h]) {
                 HIP_TRY(c, hipDeviceSynchronize());
@@ -620,7 +621,7 @@ int launchWalkPair(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, i
     unsigned resident = c->pairGrid[any] / (unsigned)c->share;
     if (resident < 8u) resident = 8u;
     const unsigned grid = chunks < resident ? (unsigned)chunks : resident;
-    const int ovfDepth = c->ds.treeDepth >= kPairLds ? c->ds.treeDepth - kPairLds + 1 : 1;
+    const int ovfDepth = c->ds.treeDepth + 1;  // entry numbers, not rows beyond the ring (traverse.h, pairPush)
     const size_t need = (size_t)std::max(c->pairGrid[0], c->pairGrid[1]) * 64 * (size_t)ovfDepth * 2;
     if (need > c->treeOvfInts) {
         if (c->treeOvf) {
@@ -691,7 +692,7 @@ int rdh_create(rdh_ctx **out, int device) {
         delete c;
         return RDH_ERR_NO_DEVICE;
     }
-    if (const char *e = getenv("RADISH_TREE")) c->treeMode = atoi(e) != 0 ? 1 : 0;  // experiments: force the shared-tree walks on / off
+    if (const char *e = getenv("RADISH_PAIRS")) c->pairMode = atoi(e) != 0 ? 1 : 0;  // experiments: force the sibling-pair walks on / off
     *out = c;
     return RDH_OK;
 }
@@ -1944,9 +1945,9 @@ static int walkPersistent(rdh_ctx *c, const float *d_rays, int64_t n, int4 *d_hi
         return timeEnd(c, what);
     }
     timeBegin(c);
-    int rc = (flags & RDH_PT_PAIRS)                         ? launchWalkPair(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
-             : ((flags & RDH_PT_TREE) || useTree(c, flags)) ? launchWalkTree(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
-                                                            : launchWalk(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0);
+    int rc = (flags & RDH_PT_TREE)                           ? launchWalkTree(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
+             : ((flags & RDH_PT_PAIRS) || usePairs(c, flags)) ? launchWalkPair(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
+                                                              : launchWalk(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0);
     if (rc) return rc;
     return timeEnd(c, what);
 }
