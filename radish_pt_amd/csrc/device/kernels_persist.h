@@ -179,17 +179,25 @@ __global__ __launch_bounds__(kScheduleThreads) void k_persist_schedule(unsigned 
 #define PH_MARK(i) do { } while (0)
 #define PH_COUNT(i, mask) do { } while (0)
 #endif
-template <bool COUNT>
-__global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
+// PAIRS: the per-lane walks go over the sibling pairs (DScene::pairs; traverse.h, pairStep) instead of the six threaded arrays:
+// same triangle tests in the same order, same counters; chosen by the host for big scenes (radish_hip.hip, usePairs).
+#ifndef RD_PERSIST_PAIR_WAVES
+#define RD_PERSIST_PAIR_WAVES 3  // the pair variant is held to three waves per SIMD (173 VGPRs otherwise: two)
+#endif
+template <bool COUNT, bool PAIRS = false>
+__global__ __launch_bounds__(64, PAIRS && !COUNT ? RD_PERSIST_PAIR_WAVES : RD_PERSIST_WAVES) void k_pt_persistent(DScene s, DCamera cam, PixelMap pm, int looper, int iter, int maxDepth,
                                                        float *__restrict__ directIllum, float *__restrict__ indirectIllum,
                                                        PersistCounters *pc, const int *__restrict__ blockOrder,
-                                                       unsigned *__restrict__ blockCost) {
+                                                       unsigned *__restrict__ blockCost, int2 *__restrict__ pairOvf = nullptr,
+                                                       int pairOvfDepth = 0) {
     // ---- LDS-resident path state (SoA: lane-consecutive, conflict-free) ----
     // One wave per workgroup: nothing here needs a workgroup barrier, and a finished wave frees its CU slot at once
     // (with 4-wave workgroups the slot stays taken until the slowest of the four has drained its last path).
     __shared__ float sThr[3][64], sAccD[3][64], sAccI[3][64], sCur[3][64];
     __shared__ float sExtO[3][64], sExtD[3][64], sExtPdf[64], sNee[4][64];
     __shared__ int sFlags[64];  // bit0: extension ray pending, bit1: that sample was specular
+    __shared__ int2 sStack[PAIRS ? kPairLds * 64 : 1];  // PAIRS: the lanes' stacks (traverse.h, pairPush)
+    int2 *const ovf = PAIRS ? pairOvf + (size_t)blockIdx.x * (size_t)pairOvfDepth * 64 : nullptr;
     const int t = int(threadIdx.x);
     const int lane = t & 63;
     const int end = s.bvhSize;
@@ -242,11 +250,14 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
     const char *nodeBase = reinterpret_cast<const char *>(s.nodes[0]);
     const unsigned ordStride = (unsigned)(s.bvhSize + 1) * (unsigned)sizeof(NodeRec);
     unsigned stepMark = 0, waveSteps = 0;  // wave-uniform count of box-loop iterations: the path's cost is how many it was in flight for
-    int node = end, pending = -1;
+    int node = end, pending = -1;  // PAIRS: `node` is the pair to enter next (pairStep's `cur`), `ordOfs` the ordering itself
+    PairStack stack{0, 0};
     float tmax = 0.f;
     int hitPrim = -1;
     v2 hitBary = mk2(0.f, 0.f);
     bool isShadow = false, occluded = false;
+    // is this lane's walk over?  (threaded: the position has reached the end of the array; pairs: nothing to enter, nothing stacked)
+    auto walkOver = [&]() { return PAIRS ? (node == kPairNone && stack.sp == 0) : (node == end); };
 
     auto startTrace = [&](const Ray &ray, float limit, bool shadow) {
         {
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
             rayD = r.d;
             rayCls = r.cls;
         }
-        ordOfs = (unsigned)getMTBVHId(-ray.d) * ordStride;
+        ordOfs = (unsigned)getMTBVHId(-ray.d) * (PAIRS ? 1u : ordStride);
         stepMark = waveSteps;
         node = 0;
         pending = -1;
@@ -264,6 +275,11 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         tmax = limit;
         isShadow = shadow;
         state = PS_TRACE;
+        if (PAIRS) {
+            stack = PairStack{0, 0};
+            if (rayCls == 0 || end == 0) pairStart<COUNT>(s, slab(), limit, node, pending, ws);  // the root's box
+            else node = kPairFresh;  // a literal-class ray: traced whole below
+        }
     };
     auto startShadow = [&](v3 x, v3 y) {  // DevScene::testOcclusion's ray set-up (scene.h:304-311)
         v3 dir = y - x;
@@ -342,6 +358,12 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                         nClosest++;
                         startTrace(ray, 3.402823466e+38f, false);
 #ifndef RD_NO_ROOT_SHORTCUT
+                        if (PAIRS) {  // the root has been tested by startTrace
+                            if (rayCls == 0 && end != 0 && node == kPairNone && pending < 0) {
+                                sAccD[0][t] = sAccD[1][t] = sAccD[2][t] = 1.f;
+                                finishPixel();
+                            }
+                        } else
                         // A primary ray that misses the root box is finished here and now: the walk would visit the root, miss
                         // it, follow its link to the end of the array, and the shading step would write direct = 1
                         // (pathtrace.cu:169-172).  More than half of the Cornell frame's pixels are such rays; taking them
@@ -378,7 +400,8 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         PH_MARK(0);
         // ---------------- literal-class rays: traced whole by the whole wave (traverse.h, coopTraceWhole) ----------------
         {
-            unsigned long long lit = __ballot(state == PS_TRACE && rayCls != 0 && node == 0 && pending < 0 && end != 0);
+            unsigned long long lit = __ballot(PAIRS ? (state == PS_TRACE && node == kPairFresh)
+                                                    : (state == PS_TRACE && rayCls != 0 && node == 0 && pending < 0 && end != 0));
 #ifdef RD_PERSIST_STAMPS
             const unsigned long long litT0 = wall_clock64();
             litRays += (unsigned long long)__popcll(lit);
@@ -387,7 +410,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                 const int L = __ffsll((long long)lit) - 1;
                 lit &= lit - 1ull;
                 const bool shadowL = readlaneI(isShadow ? 1 : 0, L) != 0;
-                const NodeRec *un = reinterpret_cast<const NodeRec *>(nodeBase + (unsigned)readlaneI((int)ordOfs, L));
+                const NodeRec *un = reinterpret_cast<const NodeRec *>(nodeBase + (unsigned)readlaneI((int)ordOfs, L) * (PAIRS ? ordStride : 1u));
                 const RaySlab ur = readlaneRay(slab(), L);
                 const float lim = readlaneF(tmax, L);
                 CoopTrace ct = shadowL ? coopTraceWhole<true>(s, un, ur, lim) : coopTraceWhole<false>(s, un, ur, lim);
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
                     hitBary = ct.bary;
                     tmax = ct.tmax;
                     occluded = ct.found;
-                    node = end;
+                    node = PAIRS ? kPairNone : end;
                     if (COUNT) {
                         ws.nodes += ct.nodes;
                         ws.tris += ct.tris;
@@ -411,7 +434,23 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         // ---------------- box steps ----------------
         // Run until a quarter of the lanes that entered the loop have stopped walking (parked on a leaf or finished
         // their ray): one ballot + popcount per step is the whole scheduling cost.
-        {
+        if (PAIRS) {
+            bool busy = state == PS_TRACE && pending < 0 && !walkOver();
+            const int nStart = __popcll(__ballot(busy));
+            if (nStart > 0) {
+                const int minWalk = (nStart * (RD_PT_LEAF_DEN - 1) + RD_PT_LEAF_DEN - 1) / RD_PT_LEAF_DEN;
+                const RaySlab rs = slab();
+                do {
+                    PH_COUNT(8, __ballot(busy));
+                    waveSteps++;
+                    pairPopOne<COUNT>(sStack, lane, ovf, tmax, busy, node, stack, pending, ws);
+                    if (busy && node >= 0) {
+                        pairStep<COUNT>(s.pairs, sStack, lane, ovf, rs, tmax, (int)ordOfs, node, stack, pending, ws);
+                        busy = pending < 0 && (node >= 0 || stack.sp > 0);
+                    }
+                } while (__popcll(ballotb(busy)) >= (minWalk > 1 ? minWalk : 1));
+            }
+        } else {
             bool walking = state == PS_TRACE && pending < 0 && node != end;
             int nStart = __popcll(__ballot(walking));
             if (nStart == 1) {
@@ -468,7 +507,8 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
             if (hit && dist < tmax) {
                 if (isShadow) {
                     occluded = true;
-                    node = end;
+                    node = PAIRS ? kPairNone : end;
+                    stack = PairStack{0, 0};
                 } else {
                     hitPrim = pending;
                     tmax = dist;
@@ -479,7 +519,7 @@ __global__ __launch_bounds__(64, RD_PERSIST_WAVES) void k_pt_persistent(DScene s
         }
         PH_MARK(3);
         // ---------------- retire finished traces ----------------
-        if (state == PS_TRACE && pending < 0 && node == end) {
+        if (state == PS_TRACE && pending < 0 && walkOver()) {
             pathSteps += waveSteps - stepMark;
             if (isShadow) {
                 float nw = sNee[3][t];

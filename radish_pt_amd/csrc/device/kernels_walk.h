@@ -526,8 +526,8 @@ __global__ __launch_bounds__(64) void k_walk_pair(DScene s, const float *__restr
             if (nStart > 0) {
                 const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
                 do {
-                    pairPops<COUNT>(stk, lane, ovf, tmax, busy, cur, sp, pending, ws);
-                    if (busy) {  // cur >= 0
+                    pairPopOne<COUNT>(stk, lane, ovf, tmax, busy, cur, sp, pending, ws);
+                    if (busy && cur >= 0) {
                         pairStep<COUNT>(s.pairs, stk, lane, ovf, rs, tmax, ord, cur, sp, pending, ws);
                         busy = pending < 0 && (cur >= 0 || sp.sp > 0);
                     }

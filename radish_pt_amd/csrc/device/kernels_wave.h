@@ -392,8 +392,8 @@ __global__ __launch_bounds__(256, PAIRS && !COUNT ? RD_WF_PAIR_WAVES : 1) void k
                 const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
                 const int lane = int(threadIdx.x & 63u);
                 do {
-                    pairPops<COUNT>(stk, lane, ovf, tmax, busy, cur, sp, pending, ws);
-                    if (busy) {
+                    pairPopOne<COUNT>(stk, lane, ovf, tmax, busy, cur, sp, pending, ws);
+                    if (busy && cur >= 0) {
                         pairStep<COUNT>(s.pairs, stk, lane, ovf, rs, tmax, ord, cur, sp, pending, ws);
                         busy = pending < 0 && (cur >= 0 || sp.sp > 0);
                     }

@@ -689,21 +689,28 @@ constexpr int kPairNone = -1, kPairFresh = -2;  // `cur`: nothing to enter / a l
 struct PairStack {
     int sp, lo;  // entries on the stack; how many of them (the oldest) are in global memory
 };
+// (Explicit address spaces: left generic, the compiler folds "ring or global" into ONE flat load through a selected pointer, which
+// waits on both memory counters; these are a ds_read_b64 / ds_write_b64 and, in the rare branch, a global access.)
+typedef int stackWord2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) stackWord2 LdsWord2;
+typedef __attribute__((address_space(1))) stackWord2 GlobalWord2;
 RD_DEV void pairPush(int2 *stk, int lane, int2 *__restrict__ ovf, PairStack &st, int w, float d) {
-    if (st.sp - st.lo == kPairLds) {  // rare
-        ovf[(size_t)st.lo * 64 + lane] = stk[(st.lo & (kPairLds - 1)) * 64 + lane];
+    LdsWord2 *ring = (LdsWord2 *)stk;
+    if (st.sp - st.lo == kPairLds) {  // rare: the oldest resident entry moves out
+        ((GlobalWord2 *)ovf)[(size_t)st.lo * 64 + lane] = ring[(st.lo & (kPairLds - 1)) * 64 + lane];
         st.lo++;
     }
-    stk[(st.sp & (kPairLds - 1)) * 64 + lane] = make_int2(w, __float_as_int(d));
+    ring[(st.sp & (kPairLds - 1)) * 64 + lane] = stackWord2{w, __float_as_int(d)};
     st.sp++;
 }
 RD_DEV int2 pairPop(const int2 *stk, int lane, const int2 *__restrict__ ovf, PairStack &st) {
     st.sp--;
-    if (st.sp < st.lo) {  // rare
+    stackWord2 e = ((const LdsWord2 *)stk)[(st.sp & (kPairLds - 1)) * 64 + lane];
+    if (__builtin_expect(st.sp < st.lo, 0)) {  // rare: the entry has been moved out
         st.lo = st.sp;
-        return ovf[(size_t)st.sp * 64 + lane];
+        e = ((const GlobalWord2 *)ovf)[(size_t)st.sp * 64 + lane];
     }
-    return stk[(st.sp & (kPairLds - 1)) * 64 + lane];
+    return make_int2(e.x, e.y);
 }
 // The root: a single box, from the kernel arguments.  Class-0 rays only.  Returns true when the walk goes on.
 template <bool COUNT>
@@ -719,27 +726,26 @@ RD_DEV void pairStart(const DScene &s, const RaySlab &rs, float tmax, int &cur, 
         else cur = ~w;
     }
 }
-// Lanes with nothing to enter take the nearest far child that is still wanted; `busy` goes false when a lane parks on a leaf or
-// its walk is over.  Wave-level loop: call from uniform control flow.
+// One iteration of a busy lane (pending < 0, and cur >= 0 or entries stacked): a lane with nothing to enter pops ONE entry — the far
+// child the sequential walk reaches next — and drops it unless its box still beats the closest distance; a lane with a pair to
+// enter (also one that has just popped an inner node) does pairStep.  `busy` goes false when the lane parks on a leaf or its walk
+// is over.  (A first version popped in a wave-level loop until every lane had something to enter: the loop-carried lane
+// predicates cost more instructions than the idle slots of this form.)
 template <bool COUNT>
-RD_DEV void pairPops(const int2 *stk, int lane, const int2 *__restrict__ ovf, float tmax, bool &busy, int &cur, PairStack &sp, int &pending, WalkStats &ws) {
-    bool need = busy && cur < 0;
-    while (__ballot(need) != 0ull) {
-        if (need) {
-            if (sp.sp == 0) {
-                busy = false;
-                need = false;
-            } else {
-                const int2 e = pairPop(stk, lane, ovf, sp);
-                if (COUNT) ws.nodes++;
-                if (__int_as_float(e.y) < tmax) {
-                    need = false;
-                    if (e.x >= 0) {
-                        pending = e.x;
-                        busy = false;
-                    } else {
-                        cur = ~e.x;
-                    }
+RD_DEV void pairPopOne(const int2 *stk, int lane, const int2 *__restrict__ ovf, float tmax, bool &busy, int &cur, PairStack &sp, int &pending,
+                       WalkStats &ws) {
+    if (busy && cur < 0) {
+        if (sp.sp == 0) {
+            busy = false;
+        } else {
+            const int2 e = pairPop(stk, lane, ovf, sp);
+            if (COUNT) ws.nodes++;
+            if (__int_as_float(e.y) < tmax) {
+                if (e.x >= 0) {
+                    pending = e.x;
+                    busy = false;
+                } else {
+                    cur = ~e.x;
                 }
             }
         }
@@ -760,7 +766,7 @@ RD_DEV void pairStep(const PairRec *__restrict__ pairs, int2 *stk, int lane, int
     const bool h1 = aabbFast(b0, b1, rs, d1) && d1 < tmax;
     const bool second = ((__float_as_int(a1.w) >> ord) & 1) != 0;  // this ordering visits child 1 first
     const int wN = __float_as_int(second ? b0.w : a0.w), wF = __float_as_int(second ? a0.w : b0.w);
-    const bool hN = second ? h1 : h0, hF = second ? h0 : h1;
+    const bool hN = (second & h1) | (!second & h0), hF = (second & h0) | (!second & h1);  // lane masks: scalar and / or
     const float dF = second ? d0 : d1;
     if (COUNT) ws.nodes++;  // the near child, now; the far one when it is popped
     if (hF || COUNT) pairPush(stk, lane, ovf, sp, wF, hF ? dF : __builtin_inff());

@@ -46,6 +46,7 @@ struct rdh_ctx {
     Counters *dCounters = nullptr;
     PersistCounters *dPersist = nullptr;
     unsigned persistGrid = 0;
+    unsigned persistGridPair = 0;  // resident waves of k_pt_persistent<false, true>
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
     unsigned treeGrid[2] = {0, 0};  // ... of k_walk_tree<false, false / true>
@@ -1017,9 +1018,29 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
             if (perCU < 1) perCU = 1;
             c->persistGrid = (unsigned)(perCU * cus);
         }
-        unsigned residentGrid = c->persistGrid / (unsigned)c->share;
+        const bool pairs = usePairs(c, flags);
+        if (pairs && c->persistGridPair == 0) {
+            int perCU = 0, cus = 0;
+            HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_pt_persistent<false, true>), 64, 0));
+            HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            if (perCU < 1) perCU = 1;
+            c->persistGridPair = (unsigned)(perCU * cus);
+        }
+        unsigned residentGrid = (pairs ? c->persistGridPair : c->persistGrid) / (unsigned)c->share;
         if (residentGrid < 8u) residentGrid = 8u;
         unsigned grid = groups < residentGrid ? groups : residentGrid;
+        const int ovfDepth = c->ds.treeDepth + 1;
+        if (pairs) {  // the walkers' stacks beyond their LDS rings (traverse.h, pairPush)
+            const size_t need = (size_t)c->persistGridPair * 64 * (size_t)ovfDepth * 2;
+            if (need > c->treeOvfInts) {
+                HIP_TRY(c, hipDeviceSynchronize());
+                if (c->treeOvf) hipFree(c->treeOvf);
+                c->treeOvf = nullptr;
+                c->treeOvfInts = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->treeOvf, need * sizeof(int)));
+                c->treeOvfInts = need;
+            }
+        }
         // longest-paths-first schedule from the previous launch's per-block costs (same partition and resolution only)
         if (c->costBlocks != pm.numBlocks) {
             HIP_TRY(c, hipStreamSynchronize(c->sideStream));
@@ -1058,12 +1079,19 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
         const int *order = useOrder ? c->blockOrder[cb] : nullptr;
         long pp = profBegin(c, flags);
-        if (count)
+        int2 *const ovf = reinterpret_cast<int2 *>(c->treeOvf);
+        if (pairs && count)
+            hipLaunchKernelGGL((k_pt_persistent<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb], ovf, ovfDepth);
+        else if (pairs)
+            hipLaunchKernelGGL((k_pt_persistent<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb], ovf, ovfDepth);
+        else if (count)
             hipLaunchKernelGGL(k_pt_persistent<true>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
-                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb], (int2 *)nullptr, 0);
         else
             hipLaunchKernelGGL(k_pt_persistent<false>, dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, pm, looper, iter,
-                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb]);
+                               maxDepth, d_direct, d_indirect, c->dPersist, order, c->blockCost[cb], (int2 *)nullptr, 0);
         profEnd(c, pp);
         // this launch's costs -> running means -> block order for launch n + 2, on the side stream
         HIP_TRY(c, hipEventRecord(c->evFrame, c->stream));
