@@ -108,14 +108,13 @@ typedef struct rdh_counters {
                                   (k_restir_pass1), instead of raygen / walk / RIS / walk / resolve (default; same results) */
 #define RDH_PT_WF_SMALL_LISTS 4096u /* wavefront only, for tests: the per-stage lists of literal-class rays hold 4 entries, so that the
                                   overflow path (such rays stay in the ordinary queues) runs */
-#define RDH_PT_TREE 8192u      /* per-lane walks over the SHARED tree (one 32-byte record per node for all six orderings, pending far
-                                  children on a per-lane stack in LDS) instead of the six threaded arrays; same records, same counters.
+#define RDH_PT_PAIRS 32768u    /* per-lane walks over SIBLING PAIRS (one 64-byte record per inner node, shared by the six orderings: a lane
+                                  that enters a node fetches both children and tests both boxes in one round trip; the far child is
+                                  re-checked when the walk reaches it) instead of the six threaded arrays; same records, same counters.
                                   Default: by scene size (>= 100 000 nodes).  rdh_trace_closest / rdh_trace_occluded (with
-                                  RDH_PT_PERSISTENT) return RDH_ERR_UNSUPPORTED when the uploaded arrays are not six orderings of one
-                                  binary tree; the frame entries then walk the threaded arrays */
-#define RDH_PT_NO_TREE 16384u  /* never walk the shared tree */
-#define RDH_PT_PAIRS 32768u    /* per-lane walks over SIBLING PAIRS: a lane that enters a node fetches both children (one 64-byte record)
-                                  and tests both boxes in one round trip; the far child is re-checked when the walk reaches it */
+                                  RDH_PT_PERSISTENT) return RDH_ERR_UNSUPPORTED when the uploaded arrays are not six orderings of
+                                  one binary tree; the frame entries then walk the threaded arrays */
+#define RDH_PT_NO_PAIRS 16384u /* never walk the sibling pairs */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_pt_persistent, k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read.  With

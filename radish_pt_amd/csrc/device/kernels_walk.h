@@ -227,182 +227,6 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
     if (COUNT) flushCounters(s.counters, ANY ? 0u : nRays, ANY ? nRays : 0u, nHits, ws);
 }
 
-// ---- the same walker over the SHARED tree (DScene::tree, layouts.h) -----------------------------------------------------------
-// One 32-byte record per tree node for all six orderings instead of six threaded copies: a sixth of the footprint in the L1s,
-// the L2s and the Infinity Cache.  A lane keeps the far children it still has to visit on a stack: the top entry in a register,
-// the next kTreeLds in LDS ([entry][lane], conflict-free), anything deeper (the reference's SAH variant builds trees 46-102 levels
-// deep) in a per-lane strip of global memory.  Visiting order = pre-order with the ordering's near child first = the threaded order
-// of nodes[k]: same decisions, same counters (every test of the threaded walker is run on this one too).  Literal-class rays are
-// traced whole over the threaded arrays, as before (coopTraceWhole reads 64 consecutive records of ONE ordering per round trip).
-template <bool COUNT, bool ANY, bool DEFER = false>
-__global__ __launch_bounds__(64, 7) void k_walk_tree(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,
-                                                  int *__restrict__ occluded, PersistCounters *pc, int *__restrict__ overflow,
-                                                  int overflowDepth, const int *__restrict__ deferCount = nullptr, int slotList = 0) {
-    __shared__ int stk[kTreeLds * 64];
-    const int lane = int(threadIdx.x) & 63;
-    const int end = s.bvhSize;
-    const long long chunks = (n + 63) / 64;
-    WalkStats ws{0, 0};
-    unsigned nRays = 0, nHits = 0;
-    long long curChunk = (long long)blockIdx.x;
-    int slotNext = 0;
-    const int gridWavesN = int(gridDim.x);
-    bool exhausted = curChunk >= chunks;
-    const NodeRec *__restrict__ tree = s.tree;
-    stk[lane] = kTreeEnd;  // row 0: what a walk pops last
-
-    constexpr int W_IDLE = 0, W_TRACE = 1, W_DONE = 2;
-    int state = W_IDLE;
-    long long rayIdx = 0;
-    RaySlab rs;
-    rs.o = rs.d = rs.inv = mk3(0.f);
-    rs.cls = 0;
-    int ord = 0;
-    int node = kTreeEnd, pending = -1, sp = 1, tos = kTreeEnd;
-    float tmax = 0.f;
-    int hitPrim = -1;
-    v2 hitBary = mk2(0.f, 0.f);
-    bool found = false;
-    const bool deferAll = DEFER && *deferCount <= kWalkDeferCap;
-
-    for (;;) {
-        // ---------------- new rays for idle lanes ----------------
-        const unsigned long long idleM = __ballot(state == W_IDLE);
-        const int nIdle = __popcll(idleM);
-        if (!exhausted && nIdle >= RD_WALK_REFILL_MIN) {
-            const int myRank = __popcll(idleM & laneMaskLt());
-            int taken = 0;
-            while (taken < nIdle && !exhausted) {
-                if (slotNext == 64) {
-                    int b = 0;
-                    if (lane == 0) b = atomicAdd(&pc->blockHead, 1);
-                    curChunk = (long long)__shfl(b, 0, 64) + gridWavesN;
-                    slotNext = 0;
-                    if (curChunk >= chunks) {
-                        exhausted = true;
-                        break;
-                    }
-                }
-                const int avail = 64 - slotNext;
-                const int give = (nIdle - taken) < avail ? (nIdle - taken) : avail;
-                if (state == W_IDLE && myRank >= taken && myRank < taken + give) {
-                    const long long i = curChunk * 64 + slotNext + (myRank - taken);
-                    if (i < n && (slotList == 0 || rays[6 * i] == rays[6 * i])) {  // see k_walk_persistent
-                        rayIdx = i;
-                        const v3 a = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
-                        const v3 b = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-                        Ray ray;
-                        if (ANY) {  // testOcclusion(a, b) (scene.h:303-315)
-                            v3 dir = b - a;
-                            float dist = length(dir);
-                            dir = dir / dist;
-                            ray = makeOffsetedRay(a, dir);
-                            tmax = dist - 1e-4f;
-                        } else {
-                            ray = Ray{a, b};
-                            tmax = 3.402823466e+38f;
-                        }
-                        rs = makeRaySlab(ray);
-                        ord = getMTBVHId(-ray.d);
-                        node = end != 0 ? 0 : kTreeEnd;
-                        sp = 1;
-                        tos = kTreeEnd;
-                        pending = -1;
-                        hitPrim = -1;
-                        hitBary = mk2(0.f, 0.f);
-                        found = false;
-                        if (!(DEFER && deferAll && raySetAside(rs.cls) && end != 0)) {  // else: k_trace_wg_list has this ray
-                            nRays++;
-                            state = W_TRACE;
-                        }
-                    }
-                }
-                slotNext += give;
-                taken += give;
-            }
-        }
-        if (__ballot(state != W_IDLE) == 0ull) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---------------- literal-class rays: traced whole by the whole wave, over the threaded array of their ordering ----------------
-        {
-            unsigned long long lit = __ballot(state == W_TRACE && rs.cls != 0 && node == 0 && sp == 1 && tos == kTreeEnd && pending < 0);
-            while (lit) {
-                const int L = __ffsll((long long)lit) - 1;
-                lit &= lit - 1ull;
-                const NodeRec *nodes = s.nodes[0] + (size_t)readlaneI(ord, L) * (size_t)(end + 1);
-                CoopTrace ct = coopTraceWhole<ANY>(s, nodes, readlaneRay(rs, L), readlaneF(tmax, L));
-                if (lane == L) {
-                    hitPrim = ct.hitPrim;
-                    hitBary = ct.bary;
-                    tmax = ct.tmax;
-                    found = ct.found;
-                    node = kTreeEnd;
-                    if (COUNT) {
-                        ws.nodes += ct.nodes;
-                        ws.tris += ct.tris;
-                    }
-                }
-            }
-        }
-        // ---------------- box steps ----------------
-        {
-            bool walking = state == W_TRACE && pending < 0 && node != kTreeEnd;
-            const int nStart = __popcll(__ballot(walking));
-            if (nStart > 0) {
-                const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
-                do {
-                    if (walking) {
-                        if (COUNT) ws.nodes++;
-                        treeBoxStep(tree, stk, lane, overflow + (size_t)blockIdx.x * (size_t)overflowDepth * 64, rs, tmax, ord, node, sp, tos, pending);
-                        walking = pending < 0 && node != kTreeEnd;
-                    }
-                } while (__popcll(__ballot(walking)) >= (minWalk > 1 ? minWalk : 1));
-            }
-        }
-        // ---------------- leaf tests ----------------
-        if (state == W_TRACE && pending >= 0) {
-            TriVerts tv = loadTri(s.tris, pending);
-            float dist;
-            v2 bary;
-            if (COUNT) ws.tris++;
-            bool hit = intersectTriangle(rs, tv.a, tv.b, tv.c, bary, dist);
-            if (hit && dist < tmax) {
-                if (ANY) {
-                    found = true;
-                    node = kTreeEnd;
-                } else {
-                    hitPrim = pending;
-                    tmax = dist;
-                    hitBary = bary;
-                }
-            }
-            pending = -1;
-        }
-        if (state == W_TRACE && pending < 0 && node == kTreeEnd) state = W_DONE;
-        // ---------------- records of finished rays ----------------
-        {
-            const unsigned long long doneM = __ballot(state == W_DONE);
-            const int nBusy = __popcll(__ballot(state != W_IDLE));
-            if (doneM != 0ull && __popcll(doneM) * 64 >= nBusy * RD_WALK_FINISH_MIN) {
-                if (state == W_DONE) {
-                    if (ANY) {
-                        occluded[rayIdx] = found ? 1 : 0;
-                    } else {
-                        const bool hit = hitPrim != -1;
-                        if (hit) nHits++;
-                        hits[rayIdx] = make_int4(hitPrim, __float_as_int(hit ? hitBary.x : 0.f), __float_as_int(hit ? hitBary.y : 0.f),
-                                                 __float_as_int(hit ? tmax : 3.402823466e+38f));
-                    }
-                    state = W_IDLE;
-                }
-            }
-        }
-    }
-    if (COUNT) flushCounters(s.counters, ANY ? 0u : nRays, ANY ? nRays : 0u, nHits, ws);
-}
-
 // ---- the same walker over SIBLING PAIRS (DScene::pairs; traverse.h, pairStep) ---------------------------------------------------
 template <bool COUNT, bool ANY, bool DEFER = false>
 __global__ __launch_bounds__(64) void k_walk_pair(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,

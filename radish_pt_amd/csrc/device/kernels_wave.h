@@ -55,7 +55,7 @@ struct WaveWorkspace {
     int *shadowq;
     int *litq[2];     // path slots of rays that look literal-class (bit 30: a shadow ray); trace(k) starts them first, one per wave
     int litCap;       // entries a stage may hold: min(kWfLitCap, 64 * waves of the trace grid)
-    int *treeOvf;     // k_wf_trace<.., true>: the deep end of its lanes' stacks, [wave of the grid][treeOvfDepth][64] (traverse.h, treeBoxStep)
+    int *treeOvf;     // k_wf_trace<.., true>: its lanes' stacks beyond their LDS rings, [wave of the grid][treeOvfDepth][64] int2 (traverse.h, pairPush)
     int treeOvfDepth;
     WaveCounters *ctr;
 };

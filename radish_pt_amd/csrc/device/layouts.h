@@ -68,20 +68,11 @@ struct Counters {
     unsigned long long closestRays, anyRays, nodeVisits, triTests, closestHits;
 };
 
-// The same tree ONCE, for the per-lane walks (round 3): record b = box of tree node b; lo_prim.w = primitiveId of a leaf, or
-// ~c for an inner node whose two children are records c and c + 1; hi_next.w = six bits, bit k set when ordering k
-// (src/bvh.cpp:171-180) visits child c + 1 first.  A walk keeps its pending far children on a small per-lane stack (LDS) instead
-// of following a per-ordering miss link, so all six orderings share 32 B per node instead of 6 x 32 B: the visiting order — near
-// child, its subtree, far child — is the threaded order of nodes[k] (pre-order, near child first), hence the same decisions
-// and the same counters.  Record numbering: the root is 0, a node's children are allocated as a pair when the node is reached in
-// ordering 0's pre-order (so sibling boxes share a 64-byte half line).  Null when the six arrays handed to rdh_scene_upload are
-// not six pre-orders of ONE binary tree (then every kernel walks nodes[k]).
-constexpr int kTreeEnd = -1;  // node value of a finished walk
-
-// The same tree as SIBLING PAIRS: record q = the two children of one inner node, 64 B on one 64-byte half line — both are visited
+// The tree ONCE, as SIBLING PAIRS, for the per-lane walks (round 3): record q = the two children of one inner node, 64 B on one
+// 64-byte half line, shared by the six orderings (the threaded arrays hold every box six times) — both children are visited
 // by every walk that enters the parent (the near one now, the far one when the near subtree is done), so one round trip serves
-// two visits.  w = primitiveId of a leaf child, or ~q' when the child is an inner node whose children are pair q'.  `bits` as in
-// DScene::tree: bit k set when ordering k visits child 1 first.  Pairs are numbered in ordering 0's pre-order of their parents
+// two visits.  w = primitiveId of a leaf child, or ~q' when the child is an inner node whose children are pair q'.  `bits`: bit k set when ordering k
+// (src/bvh.cpp:171-180) visits child 1 first.  Pairs are numbered in ordering 0's pre-order of their parents
 // (the root's pair is 0).  The root itself — a box every walk tests first — travels in DScene (kernel arguments, no load).
 struct __attribute__((aligned(64))) PairRec {
     float4 lo0_w0;    // child 0: pMin.xyz, w
@@ -93,9 +84,9 @@ static_assert(sizeof(PairRec) == 64, "PairRec");
 
 struct DScene {
     const NodeRec *nodes[6];  // one allocation: nodes[k] = nodes[0] + k * (bvhSize + 1)
-    const NodeRec *tree;      // bvhSize (+1 pad) records, or null
+    const PairRec *pairs;     // (bvhSize - 1) / 2 records; null when the six arrays handed to rdh_scene_upload are not six pre-orders
+                              // of ONE binary tree (then every kernel walks nodes[k])
     int treeDepth;            // most far children any walk can have pending at once (over the six orderings)
-    const PairRec *pairs;     // (bvhSize - 1) / 2 records, or null (exactly when `tree` is null)
     float4 rootLo, rootHi;    // the root's box; rootLo.w = its w (a one-triangle scene has a leaf root)
     const TriRec *tris;
     const AttrRec *attrs;

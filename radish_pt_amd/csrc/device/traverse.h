@@ -604,61 +604,6 @@ RD_DEV bool traceOccluded(const DScene &s, v3 x, v3 y, WalkStats &ws, bool activ
     return walkRay<COUNT, true>(s, ray, dist, h, ws, active);
 }
 
-// ---- one box step over the SHARED tree (DScene::tree, layouts.h) ---------------------------------------------------------------
-// Per-lane walk state: `node` (record number, kTreeEnd when the walk is over), `tos` = the far child that comes next when this
-// subtree is done (the top of the lane's stack, in a register) and `sp` = the stack row the NEXT push writes; rows 1 .. sp - 1 hold
-// the far children below `tos`, row 0 holds kTreeEnd for good (so a pop needs no emptiness test).  Rows 0 .. kTreeLds - 1 live in
-// LDS (`stk`: this wave's [row][lane] block), deeper ones in this wave's strip of global memory (`ovf`: [row - kTreeLds][lane]).
-// A new ray starts with node = 0 (or kTreeEnd in an empty scene), sp = 1, tos = kTreeEnd.  Class-0 rays only (aabbFast).
-// Call for the walking lanes (divergent call sites are fine: the wave-level test below ballots the active lanes).
-#ifndef RD_TREE_LDS
-#define RD_TREE_LDS 20
-#endif
-constexpr int kTreeLds = RD_TREE_LDS;
-RD_DEV void treeBoxStep(const NodeRec *__restrict__ tree, int *stk, int lane, int *__restrict__ ovf, const RaySlab &rs, float tmax, int ord,
-                        int &node, int &sp, int &tos, int &pending) {
-    const char *tb = reinterpret_cast<const char *>(tree);
-    const unsigned ofs = (unsigned)node << 5;
-    const float4 lo = *reinterpret_cast<const float4 *>(tb + ofs);
-    const float4 hi = *reinterpret_cast<const float4 *>(tb + ofs + 16u);
-    const int w3 = __float_as_int(lo.w), w7 = __float_as_int(hi.w);
-    float boundDist;
-    const bool boundHit = aabbFast(lo, hi, rs, boundDist) && boundDist < tmax;
-    // inner node whose box is hit: on to the near child, the far one waits (row sp); anything else: the top of the stack is next
-    // and row sp - 1 becomes the top
-    const bool inner = boundHit && w3 < 0;
-    const int row = inner ? sp : sp - 1;
-    if (__builtin_expect(__ballot(row >= kTreeLds) == 0ull, 1)) {
-        if (inner) {
-            const int c0 = ~w3, nb = (w7 >> ord) & 1;
-            stk[row * 64 + lane] = tos;
-            sp++;
-            tos = c0 + (nb ^ 1);
-            node = c0 + nb;
-        } else {
-            if (boundHit) pending = w3;
-            node = tos;
-            sp--;
-            tos = stk[row * 64 + lane];
-        }
-    } else {  // rare: some lane is at the deep end of its stack
-        int *q = row >= kTreeLds ? ovf + ((size_t)(row - kTreeLds) * 64 + lane) : nullptr;
-        if (inner) {
-            const int c0 = ~w3, nb = (w7 >> ord) & 1;
-            if (q) *q = tos;
-            else stk[row * 64 + lane] = tos;
-            sp++;
-            tos = c0 + (nb ^ 1);
-            node = c0 + nb;
-        } else {
-            if (boundHit) pending = w3;
-            node = tos;
-            sp--;
-            tos = q ? *q : stk[row * 64 + lane];
-        }
-    }
-}
-
 // ---- walks over SIBLING PAIRS (DScene::pairs, layouts.h) -----------------------------------------------------------------------
 // DevScene::intersect visits the two children of an inner node one after the other — the near one (by the ray's ordering) when it
 // enters the node, the far one when the near subtree is done — and tests each box against the closest distance of THAT moment.
@@ -671,8 +616,8 @@ RD_DEV void treeBoxStep(const NodeRec *__restrict__ tree, int *stk, int lane, in
 //     hits (same strict-< ties), and with COUNT the failed far children are pushed too (distance +inf) and every far child is
 //     counted when it is popped, i.e. when the sequential walk reaches it — so an any-hit walk that ends early counts what the
 //     reference counts.
-// What it buys: half the dependent round trips per visit, and stacks a few entries deep (only far children that are hit) where the
-// one-node form (treeBoxStep) needs one entry per level of these 46-102-level trees.
+// What it buys: half the dependent round trips per visit, and stacks a few entries deep (only far children that are hit) where a
+// one-node-per-step walk over a shared tree needs one entry per level of these 46-102-level trees (measured first: profiles/r03_g_*).
 // Per-lane state: `cur` = the pair to enter next (-1: none) and the stack {sp, lo}: entries lo .. sp - 1 — the most recent, at
 // most kPairLds of them — live in LDS (`stk`: this wave's [slot][lane] block of int2, a ring indexed by entry number mod kPairLds),
 // entries 0 .. lo - 1 have been moved to this wave's strip of global memory (`ovf`: [entry][lane]).  A push that finds the ring

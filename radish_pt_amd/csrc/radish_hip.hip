@@ -49,9 +49,8 @@ struct rdh_ctx {
     unsigned persistGridPair = 0;  // resident waves of k_pt_persistent<false, true>
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
-    unsigned treeGrid[2] = {0, 0};  // ... of k_walk_tree<false, false / true>
     unsigned pairGrid[2] = {0, 0};  // ... of k_walk_pair<false, false / true>
-    int *treeOvf = nullptr;         // the deep end of the tree walkers' per-lane stacks (kernels_walk.h)
+    int *treeOvf = nullptr;         // the pair walkers' stacks beyond their LDS rings (traverse.h, pairPush), ray-batch and persistent kernels
     size_t treeOvfInts = 0;
     unsigned wfGrid[4] = {0, 0, 0, 0};  // resident workgroups of k_wf_trace<false> / <true>, (unused), k_wf_shade
     unsigned wfGridPair[2] = {0, 0};    // ... of k_wf_trace<false, true> / <true, true>
@@ -159,10 +158,12 @@ float asFloat(int32_t i) {
     return f;
 }
 
-// DScene::tree (layouts.h) from the reference-layout arrays: ONE record per tree node, shared by the six orderings.  Returns false
-// (no tree; the kernels then walk the six threaded arrays) unless bvhNodes[0..5] are six pre-orders of one binary tree over
-// boundingBoxes — which is what BVHBuilder::buildMTBVH emits (src/bvh.cpp:136-183) — that differ only in which child comes first.
-// The caller has range-checked every node already.  `depth` = the most far children a walk can have pending at once.
+// DScene::pairs (layouts.h) from the reference-layout arrays: the tree once, shared by the six orderings.  Returns false (no pairs;
+// the kernels then walk the six threaded arrays) unless bvhNodes[0..5] are six pre-orders of one binary tree over boundingBoxes —
+// which is what BVHBuilder::buildMTBVH emits (src/bvh.cpp:136-183) — that differ only in which child comes first.  The caller
+// has range-checked every node already.  `tree` = one record per node (box, w = primitiveId or ~first child, ordering bits; record
+// 0 is the root, a node's children are neighbours), from which the pairs are cut; `depth` = the most far children a walk can have
+// pending at once.
 bool buildSharedTree(const rdh_scene_desc *d, int S, std::vector<NodeRec> &tree, std::vector<PairRec> &pairs, int &depth) {
     if (S <= 0) return false;
     std::vector<int> canon((size_t)S, -1);
@@ -306,13 +307,13 @@ PixelMap makePixelMap(const rdh_ctx *c) {
     return pm;
 }
 
-// Do the per-lane walks of this launch go over the sibling pairs (DScene::pairs) or over the six threaded arrays?  Measured on each
-// scene's own frame rays (profiles/r03_h_*): Cornell (37 k nodes) 1.01x the time, teapots (201 k) 0.85x, 1 M triangles 0.67x — a
-// sixth of the footprint and half the round trips pay once the threaded arrays outgrow the L2s.  RDH_PT_PAIRS / RDH_PT_NO_TREE
-// force it either way.
-constexpr int kPairMinNodes = 100000;
+// Do the per-lane walks of this launch go over the sibling pairs (DScene::pairs) or over the six threaded arrays?  Pairs wherever
+// the uploaded arrays allow: measured on each scene's own frame rays (profiles/r03_m_*) the walker needs 0.99x the time on Cornell
+// (37 k nodes), 0.79x on teapots (201 k), 0.61x on the 1-M-triangle scene, and whole frames gain on all three in every structure
+// (a sixth of the node footprint, half the dependent round trips).  RDH_PT_NO_PAIRS / RADISH_PAIRS=0 keep the threaded walks.
+constexpr int kPairMinNodes = 0;
 bool usePairs(const rdh_ctx *c, uint32_t flags) {
-    if (!c->ds.pairs || (flags & RDH_PT_NO_TREE)) return false;
+    if (!c->ds.pairs || (flags & RDH_PT_NO_PAIRS)) return false;
     if (flags & RDH_PT_PAIRS) return true;
     if (c->pairMode >= 0) return c->pairMode != 0;
     return c->ds.bvhSize >= kPairMinNodes;
@@ -509,142 +510,84 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     return rc;
 }
 
+// The walkers' stacks beyond their LDS rings (traverse.h, pairPush): one allocation of the context, grown on demand.
+int ensureStackOverflow(rdh_ctx *c, size_t ints) {
+    if (ints <= c->treeOvfInts) return RDH_OK;
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (c->treeOvf) hipFree(c->treeOvf);
+    c->treeOvf = nullptr;
+    c->treeOvfInts = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->treeOvf, ints * sizeof(int)));
+    c->treeOvfInts = ints;
+    return RDH_OK;
+}
+
 // k_walk_persistent over a ray list (d_hits xor d_occ): as many single-wave workgroups as stay resident, lane refill.
 // deferCount / deferList (ReSTIR's lists): literal-class rays have been listed by the producer of `d_rays`; they are traced one
 // per workgroup on the side stream beside the walker, which skips them; the stream waits for both before it goes on.
 int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *d_occ, bool count, const int *deferCount = nullptr,
-               const int *deferList = nullptr, int slotList = 0) {
+               const int *deferList = nullptr, int slotList = 0, bool pairs = false) {
     const int any = d_occ ? 1 : 0;
     // everything that can fail comes BEFORE the fork, so that no error path leaves the side stream un-joined
-    if (c->walkGrid[any] == 0) {
+    if (pairs && !c->ds.pairs) return fail(c, RDH_ERR_UNSUPPORTED, "RDH_PT_PAIRS: the uploaded node arrays are not six orderings of one binary tree");
+    unsigned &resGrid = pairs ? c->pairGrid[any] : c->walkGrid[any];
+    if (resGrid == 0) {
         int perCU = 0, cus = 0;
-        if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, true>), 64, 0));
+        if (pairs && any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_pair<false, true>), 64, 0));
+        else if (pairs) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_pair<false, false>), 64, 0));
+        else if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, true>), 64, 0));
         else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_persistent<false, false>), 64, 0));
         HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        c->walkGrid[any] = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
+        resGrid = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
     }
     const unsigned long long chunks = (unsigned long long)((n + 63) / 64);
-    unsigned resident = c->walkGrid[any] / (unsigned)c->share;  // rdh_set_occupancy_share: contexts side by side on one GPU
+    unsigned resident = resGrid / (unsigned)c->share;  // rdh_set_occupancy_share: contexts side by side on one GPU
     if (resident < 8u) resident = 8u;
     const unsigned grid = chunks < resident ? (unsigned)chunks : resident;
+    const int ovfDepth = c->ds.treeDepth + 1;  // entry numbers (traverse.h, pairPush)
+    if (pairs) {
+        int rc = ensureStackOverflow(c, (size_t)resGrid * 64 * (size_t)ovfDepth * 2);
+        if (rc) return rc;
+    }
+    int2 *const ovf = reinterpret_cast<int2 *>(c->treeOvf);
     HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
+    hipError_t ew = hipSuccess;
     if (deferCount) {
         HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
-        hipError_t ew = hipStreamWaitEvent(c->sideStream, c->evFork, 0);
+        ew = hipStreamWaitEvent(c->sideStream, c->evFork, 0);
         if (ew == hipSuccess) {
             if (any && count) hipLaunchKernelGGL((k_trace_wg_list<true, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
             else if (any) hipLaunchKernelGGL((k_trace_wg_list<false, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
             else if (count) hipLaunchKernelGGL((k_trace_wg_list<true, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
             else hipLaunchKernelGGL((k_trace_wg_list<false, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
         }
-        if (any && count)
-            hipLaunchKernelGGL((k_walk_persistent<true, true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount, slotList);
-        else if (any)
-            hipLaunchKernelGGL((k_walk_persistent<false, true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount, slotList);
-        else if (count)
-            hipLaunchKernelGGL((k_walk_persistent<true, false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount, slotList);
-        else
-            hipLaunchKernelGGL((k_walk_persistent<false, false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, deferCount, slotList);
+    }
+#define RD_LAUNCH_WALK(CNT, ANYHIT, DEF)                                                                                                      \
+    do {                                                                                                                                     \
+        if (pairs)                                                                                                                           \
+            hipLaunchKernelGGL((k_walk_pair<CNT, ANYHIT, DEF>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ,          \
+                               c->dPersist, ovf, ovfDepth, deferCount, slotList);                                                            \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((k_walk_persistent<CNT, ANYHIT, DEF>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ,    \
+                               c->dPersist, deferCount, slotList);                                                                           \
+    } while (0)
+    if (deferCount) {
+        if (any && count) RD_LAUNCH_WALK(true, true, true);
+        else if (any) RD_LAUNCH_WALK(false, true, true);
+        else if (count) RD_LAUNCH_WALK(true, false, true);
+        else RD_LAUNCH_WALK(false, false, true);
         // the join is unconditional: whatever failed above, the stream goes on only after the side stream's work
         hipError_t e1 = hipEventRecord(c->evJoin, c->sideStream);
         hipError_t e2 = hipStreamWaitEvent(c->stream, c->evJoin, 0);
         if (e1 != hipSuccess || e2 != hipSuccess) hipStreamSynchronize(c->sideStream);
         HIP_TRY(c, ew);
-        HIP_TRY(c, hipGetLastError());
-        return RDH_OK;
+    } else {
+        if (any && count) RD_LAUNCH_WALK(true, true, false);
+        else if (any) RD_LAUNCH_WALK(false, true, false);
+        else if (count) RD_LAUNCH_WALK(true, false, false);
+        else RD_LAUNCH_WALK(false, false, false);
     }
-    const int *none = nullptr;
-    if (any && count)
-        hipLaunchKernelGGL((k_walk_persistent<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none, slotList);
-    else if (any)
-        hipLaunchKernelGGL((k_walk_persistent<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none, slotList);
-    else if (count)
-        hipLaunchKernelGGL((k_walk_persistent<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none, slotList);
-    else
-        hipLaunchKernelGGL((k_walk_persistent<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, none, slotList);
-    HIP_TRY(c, hipGetLastError());
-    return RDH_OK;
-}
-
-// k_walk_tree (RDH_PT_TREE): the same walk over the shared tree, DScene::tree.
-int launchWalkTree(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *d_occ, bool count) {
-    const int any = d_occ ? 1 : 0;
-    if (!c->ds.tree) return fail(c, RDH_ERR_UNSUPPORTED, "RDH_PT_TREE: the uploaded node arrays are not six orderings of one binary tree");
-    if (c->treeGrid[any] == 0) {
-        int perCU = 0, cus = 0;
-        if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_tree<false, true>), 64, 0));
-        else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_tree<false, false>), 64, 0));
-        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        c->treeGrid[any] = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
-    }
-    const unsigned long long chunks = (unsigned long long)((n + 63) / 64);
-    unsigned resident = c->treeGrid[any] / (unsigned)c->share;
-    if (resident < 8u) resident = 8u;
-    const unsigned grid = chunks < resident ? (unsigned)chunks : resident;
-    const int ovfDepth = c->ds.treeDepth > kTreeLds ? c->ds.treeDepth - kTreeLds + 1 : 1;
-    const size_t need = (size_t)std::max(c->treeGrid[0], c->treeGrid[1]) * 64 * (size_t)ovfDepth;
-    if (need > c->treeOvfInts) {
-        if (c->treeOvf) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            hipFree(c->treeOvf);
-            c->treeOvf = nullptr;
-            c->treeOvfInts = 0;
-        }
-        HIP_TRY(c, hipMalloc((void **)&c->treeOvf, need * sizeof(int)));
-        c->treeOvfInts = need;
-    }
-    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
-    const int *none = nullptr;
-    if (any && count)
-        hipLaunchKernelGGL((k_walk_tree<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, c->treeOvf, ovfDepth, none, 0);
-    else if (any)
-        hipLaunchKernelGGL((k_walk_tree<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, c->treeOvf, ovfDepth, none, 0);
-    else if (count)
-        hipLaunchKernelGGL((k_walk_tree<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, c->treeOvf, ovfDepth, none, 0);
-    else
-        hipLaunchKernelGGL((k_walk_tree<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, c->treeOvf, ovfDepth, none, 0);
-    HIP_TRY(c, hipGetLastError());
-    return RDH_OK;
-}
-
-// k_walk_pair (RDH_PT_PAIRS): the same walk over the sibling pairs, DScene::pairs.
-int launchWalkPair(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *d_occ, bool count) {
-    const int any = d_occ ? 1 : 0;
-    if (!c->ds.pairs) return fail(c, RDH_ERR_UNSUPPORTED, "RDH_PT_PAIRS: the uploaded node arrays are not six orderings of one binary tree");
-    if (c->pairGrid[any] == 0) {
-        int perCU = 0, cus = 0;
-        if (any) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_pair<false, true>), 64, 0));
-        else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_walk_pair<false, false>), 64, 0));
-        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        c->pairGrid[any] = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
-    }
-    const unsigned long long chunks = (unsigned long long)((n + 63) / 64);
-    unsigned resident = c->pairGrid[any] / (unsigned)c->share;
-    if (resident < 8u) resident = 8u;
-    const unsigned grid = chunks < resident ? (unsigned)chunks : resident;
-    const int ovfDepth = c->ds.treeDepth + 1;  // entry numbers, not rows beyond the ring (traverse.h, pairPush)
-    const size_t need = (size_t)std::max(c->pairGrid[0], c->pairGrid[1]) * 64 * (size_t)ovfDepth * 2;
-    if (need > c->treeOvfInts) {
-        if (c->treeOvf) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            hipFree(c->treeOvf);
-            c->treeOvf = nullptr;
-            c->treeOvfInts = 0;
-        }
-        HIP_TRY(c, hipMalloc((void **)&c->treeOvf, need * sizeof(int)));
-        c->treeOvfInts = need;
-    }
-    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
-    const int *none = nullptr;
-    int2 *ovf = reinterpret_cast<int2 *>(c->treeOvf);
-    if (any && count)
-        hipLaunchKernelGGL((k_walk_pair<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, ovf, ovfDepth, none, 0);
-    else if (any)
-        hipLaunchKernelGGL((k_walk_pair<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, ovf, ovfDepth, none, 0);
-    else if (count)
-        hipLaunchKernelGGL((k_walk_pair<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, ovf, ovfDepth, none, 0);
-    else
-        hipLaunchKernelGGL((k_walk_pair<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ, c->dPersist, ovf, ovfDepth, none, 0);
+#undef RD_LAUNCH_WALK
     HIP_TRY(c, hipGetLastError());
     return RDH_OK;
 }
@@ -895,15 +838,13 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
     }
     if ((rc = uploadVec(c, nodes, &c->ds.nodes[0]))) return rc;
     for (int k = 1; k < 6; k++) c->ds.nodes[k] = c->ds.nodes[0] + (size_t)k * (S + 1);
-    {  // the same tree once (layouts.h, DScene::tree) — when the six arrays ARE six pre-orders of one binary tree
+    {  // the same tree once, as sibling pairs (layouts.h, DScene::pairs) — when the six arrays ARE six pre-orders of one binary tree
         std::vector<NodeRec> tree;
         std::vector<PairRec> pairs;
         int depth = 0;
-        c->ds.tree = nullptr;
         c->ds.pairs = nullptr;
         c->ds.treeDepth = 0;
         if (buildSharedTree(d, S, tree, pairs, depth)) {
-            if ((rc = uploadVec(c, tree, &c->ds.tree))) return rc;
             if ((rc = uploadVec(c, pairs, &c->ds.pairs))) return rc;
             c->ds.treeDepth = depth;
             c->ds.rootLo = make_float4(tree[0].lo_prim.x, tree[0].lo_prim.y, tree[0].lo_prim.z,
@@ -1030,17 +971,7 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
         if (residentGrid < 8u) residentGrid = 8u;
         unsigned grid = groups < residentGrid ? groups : residentGrid;
         const int ovfDepth = c->ds.treeDepth + 1;
-        if (pairs) {  // the walkers' stacks beyond their LDS rings (traverse.h, pairPush)
-            const size_t need = (size_t)c->persistGridPair * 64 * (size_t)ovfDepth * 2;
-            if (need > c->treeOvfInts) {
-                HIP_TRY(c, hipDeviceSynchronize());
-                if (c->treeOvf) hipFree(c->treeOvf);
-                c->treeOvf = nullptr;
-                c->treeOvfInts = 0;
-                HIP_TRY(c, hipMalloc((void **)&c->treeOvf, need * sizeof(int)));
-                c->treeOvfInts = need;
-            }
-        }
+        if (pairs && (rc = ensureStackOverflow(c, (size_t)c->persistGridPair * 64 * (size_t)ovfDepth * 2))) return rc;
         // longest-paths-first schedule from the previous launch's per-block costs (same partition and resolution only)
         if (c->costBlocks != pm.numBlocks) {
             HIP_TRY(c, hipStreamSynchronize(c->sideStream));
@@ -1325,7 +1256,8 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
         const unsigned gridBlk = (nBlocks1 + 3u) / 4u;
         hipLaunchKernelGGL(k_restir_raygen, dim3(gridBlk), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, apronBlocks, sp.rays,
                            sp.deferCount, sp.deferList);
-        if ((rc = launchWalk(c, sp.rays, slots, sp.hits, nullptr, count, defer ? sp.deferCount : nullptr, sp.deferList, 1))) return rc;
+        const bool pairs = usePairs(c, flags);
+        if ((rc = launchWalk(c, sp.rays, slots, sp.hits, nullptr, count, defer ? sp.deferCount : nullptr, sp.deferList, 1, pairs))) return rc;
         const int nLights = c->ds.lightSamplerLength - (c->ds.envSamplerLength != 0 ? 1 : 0);
         const size_t ldsBytes = (size_t)nLights * sizeof(LightPre) + (size_t)c->ds.lightSamplerLength * sizeof(AliasRec);
         const bool staged = nLights > 0 && ldsBytes <= kRisLdsBytes;
@@ -1340,7 +1272,7 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
             hipLaunchKernelGGL(k_restir_ris<true>, dim3(risGrid), dim3(kRisThreads), ldsBytes, c->stream, c->ds, c->cam, pm, looper, a, apronBlocks, sp);
         else
             hipLaunchKernelGGL(k_restir_ris<false>, dim3(risGrid), dim3(kRisThreads), 0, c->stream, c->ds, c->cam, pm, looper, a, apronBlocks, sp);
-        if ((rc = launchWalk(c, sp.segs, slots, nullptr, sp.occ, count, defer ? sp.deferCount + 1 : nullptr, sp.deferList + kRestirDeferCap, 1)))
+        if ((rc = launchWalk(c, sp.segs, slots, nullptr, sp.occ, count, defer ? sp.deferCount + 1 : nullptr, sp.deferList + kRestirDeferCap, 1, pairs)))
             return rc;
         // Only from here on are the G-buffer planes and last frame's reservoirs read (temporal reuse in the resolve step, spatial
         // reuse in pass 2): exchanges of either that are still in flight on the communication stream have had the ray generation,
@@ -1973,9 +1905,7 @@ static int walkPersistent(rdh_ctx *c, const float *d_rays, int64_t n, int4 *d_hi
         return timeEnd(c, what);
     }
     timeBegin(c);
-    int rc = (flags & RDH_PT_TREE)                           ? launchWalkTree(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
-             : ((flags & RDH_PT_PAIRS) || usePairs(c, flags)) ? launchWalkPair(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0)
-                                                              : launchWalk(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0);
+    int rc = launchWalk(c, d_rays, n, d_hits, d_occ, (flags & RDH_PT_COUNT) != 0, nullptr, nullptr, 0, (flags & RDH_PT_PAIRS) || usePairs(c, flags));
     if (rc) return rc;
     return timeEnd(c, what);
 }

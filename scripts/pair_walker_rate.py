@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Experiment r03_g: k_walk_persistent (six threaded node arrays, 192 B per tree node) against k_walk_tree (ONE shared 32-byte record
-per tree node, pending far children on a per-lane LDS stack) on each scene's own frame rays (rdh_dump_rays: every closest-hit ray
+"""k_walk_persistent (six threaded node arrays, 192 B per tree node) against k_walk_pair (sibling pairs: ONE shared 64-byte record per
+inner node, both children per round trip; round 3 also measured a one-node-per-step walk over a shared tree, profiles/r03_g_*, r03_h_*)
+on each scene's own frame rays (rdh_dump_rays: every closest-hit ray
 and every occlusion segment of a depth-8 frame).  Records and counters are compared first; then hipEvent time of each, mean of 5.
 usage: tree_walker_rate.py [scene ...]   scenes: cornell teapots teasets_1m"""
 import sys, numpy as np, torch
@@ -20,8 +21,7 @@ for name in names:
     closest, segs = ctx.dump_rays(3, 8)
     nC, nA = closest.shape[0], segs.shape[0]
     res = {}
-    for label, fl in (("threaded", api.RDH_PT_PERSISTENT | api.RDH_PT_NO_TREE), ("tree", api.RDH_PT_PERSISTENT | api.RDH_PT_TREE),
-                      ("pairs", api.RDH_PT_PERSISTENT | api.RDH_PT_PAIRS)):
+    for label, fl in (("threaded", api.RDH_PT_PERSISTENT | api.RDH_PT_NO_PAIRS), ("pairs", api.RDH_PT_PERSISTENT | api.RDH_PT_PAIRS)):
         hits = torch.zeros(nC, 4, dtype=torch.int32, device="cuda")
         occ = torch.zeros(max(nA, 1), dtype=torch.int32, device="cuda")
         ctx.counters_reset()
@@ -41,7 +41,7 @@ for name in names:
         print(f"{name} {W}x{H} [{label}]: closest {nC} rays {ta:.3f} ms, any {nA} segs {tb:.3f} ms, total {ta + tb:.3f} ms -> "
               f"{c['nodeVisits'] / ((ta + tb) * 1e-3) / 1e9:.1f} G box steps/s, {(nC + nA) / ((ta + tb) * 1e-3) / 1e6:.0f} Mrays/s", flush=True)
     a = res["threaded"]
-    for k in ("tree", "pairs"):
+    for k in ("pairs",):
         b = res[k]
         same = bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2])
         print(f"{name}: {k}: records and counters equal: {same}; {k} / threaded time = {(b[3] + b[4]) / (a[3] + a[4]):.3f} "

@@ -50,11 +50,10 @@ def cornell_gpu(gpu_ctx, cornell_small):
 # traversal
 # ---------------------------------------------------------------------------------------------------------------------
 def _walker_flags(api, kernel):
-    return {"one_lane_per_ray": 0, "persistent": api.RDH_PT_PERSISTENT, "shared_tree": api.RDH_PT_PERSISTENT | api.RDH_PT_TREE,
-            "sibling_pairs": api.RDH_PT_PERSISTENT | api.RDH_PT_PAIRS}[kernel]
+    return {"one_lane_per_ray": 0, "persistent": api.RDH_PT_PERSISTENT | api.RDH_PT_NO_PAIRS, "sibling_pairs": api.RDH_PT_PERSISTENT | api.RDH_PT_PAIRS}[kernel]
 
 
-@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent", "shared_tree", "sibling_pairs"])
+@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent", "sibling_pairs"])
 def test_trace_closest_bit_exact(cornell_gpu, cornell_small, kernel):
     from radish_pt_amd import api, layouts as L
 
@@ -120,7 +119,7 @@ def test_nan_origin_ray_gets_a_record_in_every_walker(cornell_gpu, cornell_small
         assert ct["nodeVisits"] == st_o["nodeVisits"] and ct["triTests"] == st_o["triTests"]
 
 
-@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent", "shared_tree", "sibling_pairs"])
+@pytest.mark.parametrize("kernel", ["one_lane_per_ray", "persistent", "sibling_pairs"])
 def test_trace_occluded_exact(cornell_gpu, cornell_small, kernel):
     from radish_pt_amd import api
 

@@ -43,16 +43,24 @@ def test_hot_kernels_stay_under_their_occupancy_steps():
         assert hits, f"no kernel matches {prefix}"
         return hits
 
-    # (mangled-name prefix, VGPR bound, waves per SIMD it must keep); COUNT variants (tests only) are not bound
+    # (mangled-name prefix, VGPR bound, waves per SIMD it must keep, bytes of scratch allowed); COUNT variants (tests only) are not
+    # bound.  Template arguments: <COUNT, PAIRS> for k_pt_persistent / k_wf_trace, <COUNT, ANY, DEFER> for the walkers.  The
+    # sibling-pair variants (round 3) hold a 64-byte record in registers: one occupancy step below the threaded ones in the
+    # wavefront trace kernel and the closest-hit walker, and k_pt_persistent<.., true> is held to three waves by its launch bound
+    # at the price of four spilled dwords.
     budgets = [
-        ("_ZN2rd15k_pt_persistentILb0E", 168, 3),
-        ("_ZN2rd10k_wf_shadeE", 168, 3),
-        ("_ZN2rd10k_wf_traceILb0E", 72, 7),
-        ("_ZN2rd17k_walk_persistentILb0E", 72, 7),
-        ("_ZN2rd12k_restir_risILb1E", 128, 4),
-        ("_ZN2rd20k_gbuffer_persistentILb0E", 128, 4),
+        ("_ZN2rd15k_pt_persistentILb0ELb0E", 168, 3, 0),
+        ("_ZN2rd15k_pt_persistentILb0ELb1E", 168, 3, 16),
+        ("_ZN2rd10k_wf_shadeE", 168, 3, 0),
+        ("_ZN2rd10k_wf_traceILb0ELb0E", 72, 7, 0),
+        ("_ZN2rd10k_wf_traceILb0ELb1E", 80, 6, 0),
+        ("_ZN2rd17k_walk_persistentILb0E", 72, 7, 0),
+        ("_ZN2rd11k_walk_pairILb0ELb1E", 72, 7, 0),
+        ("_ZN2rd11k_walk_pairILb0ELb0E", 80, 6, 0),
+        ("_ZN2rd12k_restir_risILb1E", 128, 4, 0),
+        ("_ZN2rd20k_gbuffer_persistentILb0E", 128, 4, 0),
     ]
-    for prefix, vgprs, waves in budgets:
+    for prefix, vgprs, waves, scratch in budgets:
         for name, r in one(prefix).items():
             assert r["vgpr"] <= vgprs and r["occupancy"] >= waves, (name, r, f"budget {vgprs} VGPRs / {waves} waves per SIMD")
-            assert r["scratch"] == 0, (name, r, "spills to scratch")
+            assert r["scratch"] <= scratch, (name, r, "spills to scratch")
