@@ -31,10 +31,11 @@ roofline (SURVEY Â§8d): B = 40Â·closestRays + 28Â·anyRays + 32Â·nodeVisits + 36Â
   * wavefront with sub-frames (the default): the three pipelines' launches overlap BY DESIGN, so no single launch time means
     anything; `achieved` = B per FRAME Ã· the hipEvent span of the frame (one event pair, before the fork â†’ after the join, on the
     context's stream), dominant kernel named k_wf_trace, `launches` = frames, `span` = "frame".
-  * `traversal_only` (N = 1): k_walk_persistent timed on the warm-up frame's own ray lists; next to its Â§8(d) fraction it carries
-    `l1_request_frac` = box steps/s Ã· the measured ceiling of this record layout (two L1 requests per lane and step: 304 G box
-    steps/s, scripts/micro/gather_modes, profiles/r01_c_micro_gather_modes.txt) â€” the honest ceiling: these scenes live in
-    L2 / Infinity Cache, HBM-side traffic is a small fraction of B (`traffic`, replayed from the committed PMC passes).
+  * `traversal_only` (N = 1): the walk-only kernel (k_walk_pair: sibling-pair walks, DESIGN Â§4) timed on the warm-up frame's own
+    ray lists; next to its Â§8(d) fraction it carries `l1_request_frac` = box steps/s Ã· the measured ceiling of the record layout
+    (four dwordx4 requests per lane for the two children of a node = two L1 requests per visit, fully divergent lanes: 306 G box
+    steps/s, scripts/micro/gather_modes mode 6, profiles/r01_c_micro_gather_modes.txt) â€” the honest ceiling: these scenes live
+    in L2 / Infinity Cache, HBM-side traffic is a small fraction of B (`traffic`, replayed from the committed PMC passes).
 cpu_baseline (rank 0, N = 1): Â§8d's denominator â€” the oracle's intersect / testOcclusion over a strided sample of the SAME ray
 lists, one pinned thread, best of 3; beside it the oracle's whole pathTrace (all cores: the full frame = the parity reference of
 `parity_check`; one thread: every 8th pixel).  A parity failure exits non-zero WITHOUT printing a performance line.
@@ -56,7 +57,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-L1_BOX_STEP_CEILING_G = 304.0  # box steps/s the vector L1s can serve with 32-B NodeRec (2 requests per lane and step), chip-wide
+L1_BOX_STEP_CEILING_G = 306.0  # box steps/s the vector L1s serve at 2 requests per lane and visit, fully divergent lanes, chip-wide
+                               # (gather_modes: 53.9 ns per wave-step for 2 x dwordx4 = 304 G; 107.1 ns for the 4 x dwordx4 of a pair = 306 G)
 RESTIR_PX_BYTES = 2384  # SURVEY Â§8d: per ReSTIR pixel, both passes, excluding its two rays
 
 
@@ -350,13 +352,14 @@ def main():
     if mode == "auto" and world == 1:
         mode = "wavefront_sort2"
         mode_choice = ("auto, N = 1 -> wavefront_sort2: BASELINE config 3's named structure (material-sorted wavefront + stream compaction; three "
-                       "sub-frame pipelines); on this scene it is also the fastest structure but for its own unsorted form (DESIGN Â§6)")
+                       "sub-frame pipelines, sibling-pair walks); on this scene it is also the fastest structure but for its own unsorted form: "
+                       "7.88 ms against 7.77 unsorted, 8.66 one pipeline, 9.34 persistent (profiles/r03_m_*, DESIGN Â§6)")
     elif mode == "auto":
         mode = "persistent"
         mode_choice = ("auto, N > 1 -> persistent: a rank's share of the frame is small, and the wavefront pipeline ends nine stages per frame on "
                        "their longest ray where the persistent kernel ends once on its longest path â€” one rank's share of this frame measured "
-                       "on one GPU (scripts/partition_times.py, profiles/r03_a_partition_times_teapots.txt): 5.51 / 3.47 / 2.58 ms persistent "
-                       "against 5.89 / 4.52 / 4.05 ms wavefront_sort2 at 2 / 4 / 8 ranks (N = 1: 9.68 against 9.20).  Same pixels, bit for bit")
+                       "on one GPU (scripts/partition_times.py, profiles/r03_o_partition_times_teapots.txt): 5.45 / 3.37 / 2.60 ms persistent "
+                       "against 5.16 / 4.03 / 3.56 ms wavefront_sort2 at 2 / 4 / 8 ranks (N = 1: 9.37 against 7.91).  Same pixels, bit for bit")
     sd = make_scene(scene_name)
     cam = make_camera(scene_name, W, H)
     flags = flags_main = mode_flags(api, mode)
@@ -569,7 +572,7 @@ def main():
             with torch.cuda.stream(slots[0].stream):
                 closest, segs = ctx.dump_rays(Wm, depth)  # the warm-up frame's own rays, untimed
         if world == 1 and not args.no_traversal_only:
-            # ---- traversal only: k_walk_persistent over the frame's own ray lists ----
+            # ---- traversal only: the walk-only kernel over the frame's own ray lists ----
             with torch.cuda.stream(slots[0].stream):
                 hits = torch.zeros(closest.shape[0], 4, dtype=torch.int32, device=dev)
                 occ = torch.zeros(max(segs.shape[0], 1), dtype=torch.int32, device=dev)
@@ -593,14 +596,16 @@ def main():
             wach = wbytes / (t_ms * 1e-3) / 1e9
             steps_g = wc["nodeVisits"] / (t_ms * 1e-3) / 1e9
             out["roofline"]["traversal_only"] = {
-                "kernel": "k_walk_persistent (closest-hit list, then any-hit list)", "rays": int(closest.shape[0] + segs.shape[0]),
+                "kernel": "k_walk_pair (closest-hit list, then any-hit list)", "rays": int(closest.shape[0] + segs.shape[0]),
                 "ms": round(t_ms, 4), "algorithmic_bytes": wbytes, "achieved": round(wach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(wach / HBM_PEAK_GBS, 4), "mrays_per_s": round((closest.shape[0] + segs.shape[0]) / (t_ms * 1e-3) / 1e6, 1),
                 "box_steps_per_s_G": round(steps_g, 1),
                 "l1_request_frac": round(steps_g / L1_BOX_STEP_CEILING_G, 4), "l1_request_ceiling_G": L1_BOX_STEP_CEILING_G,
-                "l1_note": "box steps/s against what the 256 vector L1s can serve for this record layout (two requests per lane and step, "
-                           "27 ns per 64-lane request whatever its width: 304 G box steps/s, scripts/micro/gather_modes).  Of the two "
-                           "fractions this is the one with a physical ceiling at 1: the Â§8(d) byte figure has none while the nodes are served from cache",
+                "l1_note": "box steps/s against what the 256 vector L1s can serve for this record layout with fully divergent lanes (the two "
+                           "children of a node are one 64-byte record = four dwordx4 requests per lane, i.e. two requests per visit; 107 ns per "
+                           "wave-step and CU: 306 G box steps/s, scripts/micro/gather_modes mode 6).  Lanes of a wave that meet at the top of the "
+                           "tree share requests, so this fraction can pass 1 (the 1-M-triangle scene: 1.09); the Â§8(d) byte figure has no "
+                           "ceiling at all while the nodes are served from cache",
                 "sample": f"every ray of frame looper={Wm} of this workload (dumped untimed), hipEvents on the context's stream, mean of {reps}",
             }
         if world == 1 and not args.no_cpu_baseline:
@@ -728,7 +733,7 @@ def main():
                 cfgs["2"] = sub_path_trace(torch, np, api, dev, "cornell", 1920, 1080, 8, "persistent", 10, 3, 100,
                                            "BASELINE config 2: Cornell stand-in (18 444 tris), 1920x1080, 8 bounces, one persistent launch per frame")
                 cfgs["4"] = sub_restir(torch, np, api, dev, 1920, 1080, 8)
-                cfgs["5_scene_one_gpu"] = sub_path_trace(torch, np, api, dev, "teasets_1m", 3840, 2160, 8, "persistent", 3, 3, 400,
+                cfgs["5_scene_one_gpu"] = sub_path_trace(torch, np, api, dev, "teasets_1m", 3840, 2160, 8, "wavefront_sort2", 3, 3, 400,
                                                          "BASELINE config 5's scene on ONE GPU: teapots re-tessellated to 999 436 tris, 3840x2160, 8 bounces, pathTrace")
             except Exception as e:  # a sub-record must not cost the headline; say what happened
                 cfgs["error"] = f"{type(e).__name__}: {e}"
