@@ -349,17 +349,19 @@ def main():
     tile = args.tile or 64
     mode = args.mode
     mode_choice = None
-    if mode == "auto" and world == 1:
+    if mode == "auto" and world <= 2:
         mode = "wavefront_sort2"
-        mode_choice = ("auto, N = 1 -> wavefront_sort2: BASELINE config 3's named structure (material-sorted wavefront + stream compaction; three "
+        mode_choice = ("auto, N <= 2 -> wavefront_sort2: BASELINE config 3's named structure (material-sorted wavefront + stream compaction; three "
                        "sub-frame pipelines, sibling-pair walks); on this scene it is also the fastest structure but for its own unsorted form: "
-                       "7.88 ms against 7.77 unsorted, 8.66 one pipeline, 9.34 persistent (profiles/r03_m_*, DESIGN §6)")
+                       "7.88 ms against 7.77 unsorted, 8.66 one pipeline, 9.34 persistent (profiles/r03_m_*, DESIGN §6).  It is what the "
+                       "library's own RDH_PT_AUTO picks for this tree and this share of the frame")
     elif mode == "auto":
         mode = "persistent"
-        mode_choice = ("auto, N > 1 -> persistent: a rank's share of the frame is small, and the wavefront pipeline ends nine stages per frame on "
-                       "their longest ray where the persistent kernel ends once on its longest path — one rank's share of this frame measured "
-                       "on one GPU (scripts/partition_times.py, profiles/r03_o_partition_times_teapots.txt): 5.45 / 3.37 / 2.60 ms persistent "
-                       "against 5.16 / 4.03 / 3.56 ms wavefront_sort2 at 2 / 4 / 8 ranks (N = 1: 9.37 against 7.91).  Same pixels, bit for bit")
+        mode_choice = ("auto, N >= 4 -> persistent (the library's RDH_PT_AUTO rule: a big tree AND at least half a 1080p frame -> wavefront, else "
+                       "persistent): a rank's share of the frame is small, and the wavefront pipeline ends nine stages per frame on their longest "
+                       "ray where the persistent kernel ends once on its longest path — one rank's share of this frame measured on one GPU "
+                       "(scripts/partition_times.py, profiles/r03_o_partition_times_teapots.txt): 5.45 / 3.37 / 2.60 ms persistent against "
+                       "5.16 / 4.03 / 3.56 ms wavefront_sort2 at 2 / 4 / 8 ranks (N = 1: 9.37 against 7.91).  Same pixels, bit for bit")
     sd = make_scene(scene_name)
     cam = make_camera(scene_name, W, H)
     flags = flags_main = mode_flags(api, mode)

@@ -115,6 +115,10 @@ typedef struct rdh_counters {
                                   RDH_PT_PERSISTENT) return RDH_ERR_UNSUPPORTED when the uploaded arrays are not six orderings of
                                   one binary tree; the frame entries then walk the threaded arrays */
 #define RDH_PT_NO_PAIRS 16384u /* never walk the sibling pairs */
+#define RDH_PT_AUTO 65536u     /* rdh_path_trace / rdh_path_trace_gathered*: the library picks the structure by what this launch holds —
+                                  the wavefront pipeline with material sort and three sub-frames for a big tree (>= 100 000 nodes) and a
+                                  big share of the frame (>= 12 000 8x8 blocks: a 1080p frame, or half of one), else the persistent kernel
+                                  (measured: DESIGN 5d, 8).  Same pixels either way; other structure bits are ignored with it */
 #define RDH_PT_NO_SCHEDULE 32u /* persistent only: ignore the longest-paths-first block order of the previous launch   */
 #define RDH_PT_PROFILE 8u      /* bracket each launch of the traversal kernel (k_pt_persistent, k_wf_trace, or the megakernel)
                                   with hipEvents on the context's stream; read with rdh_profile_read.  With

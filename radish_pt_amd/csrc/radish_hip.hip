@@ -939,6 +939,11 @@ int rdh_path_trace(rdh_ctx *c, float *d_direct, float *d_indirect, int iter, int
     HIP_TRY(c, hipSetDevice(c->device));
     PixelMap pm = makePixelMap(c);
     const bool count = (flags & RDH_PT_COUNT) != 0;
+    if (flags & RDH_PT_AUTO) {  // the structure by what this launch holds (radish_hip.h; measured: DESIGN 5d, 8)
+        flags &= ~(RDH_PT_AUTO | RDH_PT_WAVEFRONT | RDH_PT_SORT_MATERIAL | RDH_PT_WF_SUBFRAMES | RDH_PT_PERSISTENT);
+        const bool wavefront = c->ds.bvhSize >= 100000 && pm.numBlocks >= 12000;
+        flags |= wavefront ? (RDH_PT_WAVEFRONT | RDH_PT_SORT_MATERIAL | RDH_PT_WF_SUBFRAMES) : RDH_PT_PERSISTENT;
+    }
     if (flags & RDH_PT_WAVEFRONT) {
         rc = wavefrontEnsure(c, pm);
         if (rc) return rc;

@@ -177,16 +177,16 @@ inline void pathTrace(glm::vec3 *directIllum, glm::vec3 *indirectIllum, int iter
         iF.push_back(p.indirect);
     }
     RADISH_CHECK(rdh_path_trace_gathered_all(all.data(), (int)all.size(), dF.data(), iF.data(), iter, State::looper, Settings::traceDepth,
-                                             RDH_PT_PERSISTENT),
+                                             RDH_PT_AUTO),
                  "pathTrace");
     for (radish_shim::Peer &p : radish_shim::peers()) RADISH_CHECK(rdh_synchronize(p.c), "pathTrace");
 #elif defined(RADISH_SHIM_MULTI_GPU)
     RADISH_CHECK(rdh_path_trace_gathered(c, reinterpret_cast<float *>(directIllum), reinterpret_cast<float *>(indirectIllum), iter,
-                                         State::looper, Settings::traceDepth, RDH_PT_PERSISTENT),
+                                         State::looper, Settings::traceDepth, RDH_PT_AUTO),
                  "pathTrace");
 #else
     RADISH_CHECK(rdh_path_trace(c, reinterpret_cast<float *>(directIllum), reinterpret_cast<float *>(indirectIllum), iter,
-                                State::looper, Settings::traceDepth, RDH_PT_PERSISTENT),
+                                State::looper, Settings::traceDepth, RDH_PT_AUTO),
                  "pathTrace");
 #endif
     RADISH_CHECK(rdh_synchronize(c), "pathTrace");

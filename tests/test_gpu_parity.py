@@ -203,7 +203,7 @@ def test_workgroup_per_ray_trace_bit_exact(cornell_gpu, cornell_small):
 # ---------------------------------------------------------------------------------------------------------------------
 # pathTrace: megakernel and wavefront, several frames of accumulation
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("flags_name", ["mega", "wavefront", "wavefront_sort", "persistent"])
+@pytest.mark.parametrize("flags_name", ["mega", "wavefront", "wavefront_sort", "persistent", "persistent_threaded", "wavefront_threaded", "auto"])
 @pytest.mark.parametrize("size,depth", [((64, 48), 4), ((37, 29), 8)])
 def test_path_trace_bit_exact(cornell_gpu, cornell_small, flags_name, size, depth):
     from radish_pt_amd import api, scenes
@@ -211,7 +211,11 @@ def test_path_trace_bit_exact(cornell_gpu, cornell_small, flags_name, size, dept
     torch = _torch()
     flags = {"mega": api.RDH_PT_MEGAKERNEL, "wavefront": api.RDH_PT_WAVEFRONT,
              "wavefront_sort": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL,
-             "persistent": api.RDH_PT_PERSISTENT}[flags_name] | api.RDH_PT_COUNT
+             "persistent": api.RDH_PT_PERSISTENT,
+             # the walks over the six threaded arrays (the default since round 3 is the sibling pairs) and the library's own choice
+             "persistent_threaded": api.RDH_PT_PERSISTENT | api.RDH_PT_NO_PAIRS,
+             "wavefront_threaded": api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL | api.RDH_PT_NO_PAIRS,
+             "auto": api.RDH_PT_AUTO}[flags_name] | api.RDH_PT_COUNT
     W, H = size
     cam = scenes.cornell_camera(W, H)
     o = _oracle(cornell_small)
