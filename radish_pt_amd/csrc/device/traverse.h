@@ -711,7 +711,9 @@ RD_DEV void pairStep(const PairRec *__restrict__ pairs, int2 *stk, int lane, int
     const bool h1 = aabbFast(b0, b1, rs, d1) && d1 < tmax;
     const bool second = ((__float_as_int(a1.w) >> ord) & 1) != 0;  // this ordering visits child 1 first
     const int wN = __float_as_int(second ? b0.w : a0.w), wF = __float_as_int(second ? a0.w : b0.w);
-    const bool hN = (second & h1) | (!second & h0), hF = (second & h0) | (!second & h1);  // lane masks: scalar and / or
+    // near / far selection on LANE MASKS (scalar and / or; written with bools the compiler goes through 0 / 1 VGPR values: seven VALU)
+    const unsigned long long S = ballotb(second), H0 = ballotb(h0), H1 = ballotb(h1);
+    const bool hN = __builtin_amdgcn_inverse_ballot_w64((H1 & S) | (H0 & ~S)), hF = __builtin_amdgcn_inverse_ballot_w64((H0 & S) | (H1 & ~S));
     const float dF = second ? d0 : d1;
     if (COUNT) ws.nodes++;  // the near child, now; the far one when it is popped
     if (hF || COUNT) pairPush(stk, lane, ovf, sp, wF, hF ? dF : __builtin_inff());
