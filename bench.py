@@ -497,13 +497,17 @@ def main():
     pipelined = None
     if not args.no_pipelined and F == 1:
         Fp = 3  # the same at every N, so that this figure has a like-for-like scaling curve of its own (3 measured best on one GPU)
-        mp_ = measure(Fp, False, flags=api.RDH_PT_PERSISTENT)
-        pipelined = {"frames_in_flight": Fp, "mode": "persistent", "value": round(mp_["rays_total"] / mp_["elapsed"] / 1e6, 3), "unit": "Mrays/s",
+        # which structure: with a big share of the frame per rank, ONE wavefront pipeline per frame (three frames = three pipelines on
+        # three streams, like the headline's three sub-frames, but each stage three times as large: 6.7 ms per frame against 7.85,
+        # profiles/r03_t_*); with a small share, the persistent kernel (as the headline)
+        p_mode = "wavefront_sort" if world <= 2 else "persistent"
+        mp_ = measure(Fp, False, flags=mode_flags(api, p_mode))
+        pipelined = {"frames_in_flight": Fp, "mode": p_mode, "value": round(mp_["rays_total"] / mp_["elapsed"] / 1e6, 3), "unit": "Mrays/s",
                      "ms_per_step": round(mp_["elapsed"] / K * 1e3, 4),
-                     "note": "throughput with 3 frames in flight per GPU at every N (each on its own stream, one persistent launch per frame, "
-                             "grids divided by 3" + ("; torch.distributed collectives on one shared stream" if world > 1 else "") + "): the tail of one "
-                             "frame — a launch lasts at least one path latency, which does not shrink with a rank's share (DESIGN §8) — is filled by "
-                             "the next; not a frame latency, not the headline"}
+                     "note": "throughput with 3 frames in flight per GPU at every N (each on its own stream(s), persistent grids divided by 3"
+                             + ("; torch.distributed collectives on one shared stream" if world > 1 else "") + "): the tails of one frame's "
+                             "launches — a launch lasts at least as long as its longest path or ray, which does not shrink with the work it holds "
+                             "(DESIGN §7, §8) — are filled by the other frames; not a frame latency, not the headline"}
         for sl in mp_["slots"]:
             sl.ctx.close()
     slots = m["slots"]
