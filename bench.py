@@ -739,7 +739,7 @@ def main():
                 cfgs["2"] = sub_path_trace(torch, np, api, dev, "cornell", 1920, 1080, 8, "persistent", 10, 3, 100,
                                            "BASELINE config 2: Cornell stand-in (18 444 tris), 1920x1080, 8 bounces, one persistent launch per frame")
                 cfgs["4"] = sub_restir(torch, np, api, dev, 1920, 1080, 8)
-                cfgs["5_scene_one_gpu"] = sub_path_trace(torch, np, api, dev, "teasets_1m", 3840, 2160, 8, "wavefront_sort2", 3, 3, 400,
+                cfgs["5_scene_one_gpu"] = sub_path_trace(torch, np, api, dev, "teasets_1m", 3840, 2160, 8, "wavefront2", 3, 3, 400,
                                                          "BASELINE config 5's scene on ONE GPU: teapots re-tessellated to 999 436 tris, 3840x2160, 8 bounces, pathTrace")
             except Exception as e:  # a sub-record must not cost the headline; say what happened
                 cfgs["error"] = f"{type(e).__name__}: {e}"

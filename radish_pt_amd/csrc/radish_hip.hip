@@ -426,7 +426,8 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     // longest ray while the stages of the others fill the chip.  Each pipeline launches a third of the resident grid.  Measured on
     // the teapots / Cornell frame: one pipeline 12.3 / 5.14 ms, two 10.5 / 4.70, three 10.2 / 4.58, four 10.4 / 5.0.  Small frames
     // stay one pipeline.
-    const int parts = ((flags & RDH_PT_WF_SUBFRAMES) && pm.numBlocks >= 2048) ? kWfParts : 1;
+    static const int partsEnv = getenv("RADISH_WF_PARTS") ? atoi(getenv("RADISH_WF_PARTS")) : kWfParts;  // experiments: 2
+    const int parts = ((flags & RDH_PT_WF_SUBFRAMES) && pm.numBlocks >= 2048) ? (partsEnv >= 1 && partsEnv <= kWfParts ? partsEnv : kWfParts) : 1;
     hipStream_t sts[kWfParts] = {c->stream, c->sideStream, c->wfStream};
     // persistent grids: what stays resident, shared between the sub-frame pipelines and between the contexts that render side by
     // side on this GPU (rdh_set_occupancy_share)
