@@ -715,9 +715,14 @@ RD_DEV Ray gbufPrimaryRay(const DCamera &cam, int x, int y) {
 #ifndef RD_GB_FINISH_MIN
 #define RD_GB_FINISH_MIN 16
 #endif
-template <bool COUNT, bool DEFER>
-__global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam, DCamera lastCam, PixelMap pm, GBufPtrs gb,
-                                                           PersistCounters *pc) {
+// PAIRS: the primary rays walk the sibling pairs (traverse.h, pairStep).  Coherent rays gain nothing from it while the threaded arrays
+// sit in the caches (teapots, 201 k nodes: 0.78 ms either way) — the host picks it for trees whose six threaded arrays outgrow the
+// Infinity Cache (radish_hip.hip, rdh_gbuffer_render).
+template <bool COUNT, bool DEFER, bool PAIRS = false>
+__global__ __launch_bounds__(64, PAIRS && !COUNT ? 4 : 1) void k_gbuffer_persistent(DScene s, DCamera cam, DCamera lastCam, PixelMap pm, GBufPtrs gb,
+                                                           PersistCounters *pc, int2 *__restrict__ pairOvf = nullptr, int pairOvfDepth = 0) {
+    __shared__ int2 sStack[PAIRS ? kPairLds * 64 : 1];  // PAIRS: the lanes' stacks (traverse.h, pairPush)
+    int2 *const ovf = PAIRS ? pairOvf + (size_t)blockIdx.x * (size_t)pairOvfDepth * 64 : nullptr;
     const int lane = int(threadIdx.x) & 63;
     const int end = s.bvhSize;
     const int numBlocks = pm.numBlocks;
@@ -736,11 +741,14 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
     rs.o = rs.d = rs.inv = mk3(0.f);
     rs.cls = 0;
     const NodeRec *nodes = s.nodes[0];
-    int node = end, pending = -1;
+    int node = end, pending = -1;  // PAIRS: `node` is the pair to enter next (pairStep's `cur`)
+    int ord = 0;
+    PairStack stack{0, 0};
     float tmax = 0.f;
     int hitPrim = -1;
     v2 hitBary = mk2(0.f, 0.f);
     const bool deferAll = DEFER && pc->deferCount <= kDeferCap;  // written by k_gbuffer_find_literal, earlier in the stream
+    auto walkOver = [&]() { return PAIRS ? (node == kPairNone && stack.sp == 0) : (node == end); };
 
     for (;;) {
         // ---------------- new pixels for idle lanes ----------------
@@ -781,6 +789,12 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
                         } else {
                             nClosest++;
                             state = G_TRACE;
+                            if (PAIRS) {
+                                ord = getMTBVHId(-ray.d);
+                                stack = PairStack{0, 0};
+                                if (rs.cls == 0 || end == 0) pairStart<COUNT>(s, rs, tmax, node, pending, ws);  // the root's box
+                                else node = kPairFresh;  // a literal-class ray: traced whole below
+                            }
                         }
                     }
                 }
@@ -794,7 +808,8 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
         }
         // ---------------- literal-class rays: traced whole by the whole wave ----------------
         {
-            unsigned long long lit = __ballot(state == G_TRACE && rs.cls != 0 && node == 0 && pending < 0 && end != 0);
+            unsigned long long lit = __ballot(PAIRS ? (state == G_TRACE && node == kPairFresh)
+                                                    : (state == G_TRACE && rs.cls != 0 && node == 0 && pending < 0 && end != 0));
             while (lit) {
                 const int L = __ffsll((long long)lit) - 1;
                 lit &= lit - 1ull;
@@ -803,7 +818,7 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
                     hitPrim = ct.hitPrim;
                     hitBary = ct.bary;
                     tmax = ct.tmax;
-                    node = end;
+                    node = PAIRS ? kPairNone : end;
                     if (COUNT) {
                         ws.nodes += ct.nodes;
                         ws.tris += ct.tris;
@@ -812,7 +827,20 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
             }
         }
         // ---------------- box steps ----------------
-        {
+        if (PAIRS) {
+            bool busy = state == G_TRACE && pending < 0 && !walkOver();
+            const int nStart = __popcll(__ballot(busy));
+            if (nStart > 0) {
+                const int minWalk = (nStart * (RD_LEAF_DEN - RD_LEAF_NUM) + RD_LEAF_DEN - 1) / RD_LEAF_DEN;
+                do {
+                    pairPopOne<COUNT>(sStack, lane, ovf, tmax, busy, node, stack, pending, ws);
+                    if (busy && node >= 0) {
+                        pairStep<COUNT>(s.pairs, sStack, lane, ovf, rs, tmax, ord, node, stack, pending, ws);
+                        busy = pending < 0 && (node >= 0 || stack.sp > 0);
+                    }
+                } while (__popcll(__ballot(busy)) >= (minWalk > 1 ? minWalk : 1));
+            }
+        } else {
             bool walking = state == G_TRACE && pending < 0 && node != end;
             const int nStart = __popcll(__ballot(walking));
             if (nStart == 1) {
@@ -858,7 +886,7 @@ __global__ __launch_bounds__(64) void k_gbuffer_persistent(DScene s, DCamera cam
             }
             pending = -1;
         }
-        if (state == G_TRACE && pending < 0 && node == end) state = G_DONE;
+        if (state == G_TRACE && pending < 0 && walkOver()) state = G_DONE;
         // ---------------- write the records of finished pixels ----------------
         {
             const unsigned long long doneM = __ballot(state == G_DONE);

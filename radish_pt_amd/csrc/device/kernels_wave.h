@@ -498,7 +498,10 @@ __global__ __launch_bounds__(256, PAIRS && !COUNT ? RD_WF_PAIR_WAVES : 1) void k
 // hit records.  Classes: 0 = terminal (miss / emitter / other), 1 = Lambertian, 2 = metallic workflow, 3 = dielectric.
 constexpr int kSortChunks = 16;                  // chunks of 64 records per sorted packet
 constexpr int kSortPacket = 64 * kSortChunks;    // records a wave bins at a time
-__global__ __launch_bounds__(256) void k_wf_shade(DScene s, WaveWorkspace w, int k, int maxDepth, int sorted) {
+#ifndef RD_WF_SHADE_WAVES
+#define RD_WF_SHADE_WAVES 1  // waves per SIMD k_wf_shade is held to (1: whatever its 155 VGPRs allow = 3)
+#endif
+__global__ __launch_bounds__(256, RD_WF_SHADE_WAVES) void k_wf_shade(DScene s, WaveWorkspace w, int k, int maxDepth, int sorted) {
     __shared__ int sSorted[4][kSortPacket];  // per wave of the workgroup: the packet's path slots in class order
     WaveCounters *c = w.ctr;
     const int lane = int(threadIdx.x & 63u);

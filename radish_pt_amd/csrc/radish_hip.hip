@@ -48,6 +48,7 @@ struct rdh_ctx {
     unsigned persistGrid = 0;
     unsigned persistGridPair = 0;  // resident waves of k_pt_persistent<false, true>
     unsigned gbufGrid = 0;  // resident waves of k_gbuffer_persistent
+    unsigned gbufGridPair = 0;  // ... of its sibling-pair variant
     unsigned walkGrid[2] = {0, 0};  // ... of k_walk_persistent<false, false / true>
     unsigned pairGrid[2] = {0, 0};  // ... of k_walk_pair<false, false / true>
     int *treeOvf = nullptr;         // the pair walkers' stacks beyond their LDS rings (traverse.h, pairPush), ray-batch and persistent kernels
@@ -1107,8 +1108,25 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
         HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
         c->gbufGrid = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
     }
+    // Primary rays are coherent: while the six threaded arrays sit in the caches the pair walk buys them nothing (teapots, 201 k nodes:
+    // 0.78 ms either way, profiles/r03_o_*); it is taken where those arrays outgrow the 256-MiB Infinity Cache (6 x 32 B x nodes).
+    static const int gbufPairsEnv = getenv("RADISH_GBUFFER_PAIRS") ? atoi(getenv("RADISH_GBUFFER_PAIRS")) : -1;  // experiments
+    const bool pairs = usePairs(c, flags) && (gbufPairsEnv >= 0 ? gbufPairsEnv != 0 : (size_t)c->ds.bvhSize * 192 > ((size_t)256 << 20));
+    if (pairs && c->gbufGridPair == 0) {
+        int perCU = 0, cus = 0;
+        HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_gbuffer_persistent<false, true, true>), 64, 0));
+        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->gbufGridPair = (unsigned)((perCU < 1 ? 1 : perCU) * cus);
+    }
+    const unsigned resGrid = pairs ? c->gbufGridPair : c->gbufGrid;
     unsigned groups = (((unsigned)(pm.numBlocks + 3) / 4 + 7u) / 8u) * 8u * 4u;
-    unsigned grid = groups < c->gbufGrid ? groups : c->gbufGrid;
+    unsigned grid = groups < resGrid ? groups : resGrid;
+    const int ovfDepth = c->ds.treeDepth + 1;
+    if (pairs) {
+        int rc2 = ensureStackOverflow(c, (size_t)resGrid * 64 * (size_t)ovfDepth * 2);
+        if (rc2) return rc2;
+    }
+    int2 *const ovf = reinterpret_cast<int2 *>(c->treeOvf);
     timeBegin(c);
     HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
     // literal-class rays are listed first and traced on a second stream beside the rest, each by a whole workgroup
@@ -1127,14 +1145,20 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
             hipLaunchKernelGGL(k_gbuffer_literal<false>, dim3(kDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, c->cam, last, p, c->dPersist);
         HIP_TRY(c, hipEventRecord(c->evJoin, c->sideStream));
     }
-    if (count && defer)
-        hipLaunchKernelGGL((k_gbuffer_persistent<true, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
-    else if (count)
-        hipLaunchKernelGGL((k_gbuffer_persistent<true, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
-    else if (defer)
-        hipLaunchKernelGGL((k_gbuffer_persistent<false, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
-    else
-        hipLaunchKernelGGL((k_gbuffer_persistent<false, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+#define RD_LAUNCH_GBUF(CNT, DEF)                                                                                                             \
+    do {                                                                                                                                     \
+        if (pairs)                                                                                                                           \
+            hipLaunchKernelGGL((k_gbuffer_persistent<CNT, DEF, true>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p,         \
+                               c->dPersist, ovf, ovfDepth);                                                                                  \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((k_gbuffer_persistent<CNT, DEF, false>), dim3(grid), dim3(64), 0, c->stream, c->ds, c->cam, last, pm, p,        \
+                               c->dPersist, (int2 *)nullptr, 0);                                                                             \
+    } while (0)
+    if (count && defer) RD_LAUNCH_GBUF(true, true);
+    else if (count) RD_LAUNCH_GBUF(true, false);
+    else if (defer) RD_LAUNCH_GBUF(false, true);
+    else RD_LAUNCH_GBUF(false, false);
+#undef RD_LAUNCH_GBUF
     if (defer) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evJoin, 0));
     return timeEnd(c, "renderGBuffer");
 }
