@@ -17,7 +17,10 @@
 
 namespace rd {
 
-constexpr int kWgTraceThreads = 1024;
+#ifndef RD_WG_TRACE_THREADS
+#define RD_WG_TRACE_THREADS 1024  // threads = records per window of the workgroup-per-ray launches (256 / 512 measured: profiles/r03_z3_*)
+#endif
+constexpr int kWgTraceThreads = RD_WG_TRACE_THREADS;
 constexpr int kWgTraceWords = kWgTraceThreads / 64;
 
 // THREADS = workgroup size = records per window: 1 024 for the launches that give a ray a workgroup of its own (G-buffer, ReSTIR's
