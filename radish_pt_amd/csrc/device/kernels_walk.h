@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
 
 // ---- the same walker over SIBLING PAIRS (DScene::pairs; traverse.h, pairStep) ---------------------------------------------------
 template <bool COUNT, bool ANY, bool DEFER = false>
-__global__ __launch_bounds__(64) void k_walk_pair(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,
+__global__ __launch_bounds__(64, COUNT ? 1 : 7) void k_walk_pair(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,
                                                   int *__restrict__ occluded, PersistCounters *pc, int2 *__restrict__ overflow,
                                                   int overflowDepth, const int *__restrict__ deferCount = nullptr, int slotList = 0) {
     __shared__ int2 stk[kPairLds * 64];

@@ -1,11 +1,13 @@
-mkdir -p gpurun_out/r03z3; O=gpurun_out/r03z3
+mkdir -p gpurun_out/r03z5; O=gpurun_out/r03z5
 V=$GRAFT_REPO_ROOT/radish_pt_amd/csrc/variants
-for v in base wg512 wg256; do
+timeout -k 10 200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "trace_" 2>&1 | tail -1 | tee -a $O/progress.log
+timeout -k 10 300 python scripts/pair_walker_rate.py teapots teasets_1m cornell 2>&1 | grep "pairs\]\|pairs:" | tee -a $O/progress.log
+R1=$(timeout -k 10 200 python3 bench.py --workload restir --steps 8 --no-cpu-baseline 2>/dev/null | tail -1); echo "restir config 4: $(echo $R1 | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "ms")')" | tee -a $O/progress.log
+b() { # label lib mode scene
+  R1=$(RADISH_HIP_LIB=$2 timeout -k 10 120 python3 bench.py --mode $3 --scene $4 --steps 10 --warmup 3 --no-cpu-baseline --no-pipelined --no-configs --no-traversal-only 2>/dev/null | tail -1)
+  echo "$(date +%T) $1 $4 $3: $(echo $R1 | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "ms  frac", d["roofline"]["frac"])' 2>/dev/null || echo FAILED)" | tee -a $O/progress.log
+}
+for v in base pw7 base pw7; do
   if [ $v = base ]; then L=""; else L=$V/libradish_hip_$v.so; fi
-  echo "== $v" | tee -a $O/progress.log
-  RADISH_HIP_LIB=$L timeout -k 10 200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "workgroup or gbuffer_kernels" 2>&1 | tail -1 | tee -a $O/progress.log
-  RADISH_HIP_LIB=$L timeout -k 10 200 python scripts/gbuffer_4k.py 2>&1 | grep gbuffer | tee -a $O/progress.log
-  R1=$(RADISH_HIP_LIB=$L timeout -k 10 200 python3 bench.py --workload restir --steps 8 --no-cpu-baseline 2>/dev/null | tail -1)
-  echo "restir config 4: $(echo $R1 | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "ms")' 2>/dev/null || echo FAILED)" | tee -a $O/progress.log
+  b $v "$L" wavefront_sort2 teapots; b $v "$L" wavefront_sort teapots
 done
-RADISH_HIP_LIB=$V/libradish_hip_wg256.so timeout -k 10 300 python scripts/partition_times_restir.py teasets_1m 3840 2160 2>&1 | grep '"tile": 128' | grep -v rows | tee -a $O/progress.log
