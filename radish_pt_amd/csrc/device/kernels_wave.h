@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelM
     Pix px = mapPixel(pm, inRange ? blockLocal * (unsigned)parts + (unsigned)part : 0xffffffffu / 64u, lane);
     bool valid = px.valid && inRange;
     int p = int(blockLocal * 64u + lane);  // path slot = work index (fixed for the frame)
+    bool listed = false;
     if (valid) {
         Sampler rng = makeSeededRandomEngine(looper, px.index, 0, s.sobol);
         Ray ray = cameraSample(cam, px.x, px.y, sample4D(rng));
@@ -136,10 +137,20 @@ __global__ __launch_bounds__(256) void k_wf_raygen(DScene s, DCamera cam, PixelM
         w.accD[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         w.accI[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         w.rng[p] = make_uint2(rng.scramble, (unsigned)rng.ptr);
+        // Primary rays that LOOK literal-class (the hint k_wf_shade uses for the rays it emits) go on stage 0's first list, so that a
+        // workgroup of trace(0) traces them before anything else instead of one wave meeting them late (stage 0 was where the last
+        // launches above 1 ms were: profiles/r03_w_teapots_trace_stage_time_histogram.txt).  A handful per frame: one atomic each.
+        if (fabs_(ray.d.x) < 1.1e-6f || fabs_(ray.d.y) < 1.1e-6f || fabs_(ray.d.z) < 1.1e-6f) {
+            const int at = atomicAdd(&w.ctr->litCount[0].v, 1);
+            if (at < w.litCap) {
+                w.litq[0][at] = p;
+                listed = true;
+            }
+        }
     }
-    // Bounce 0's queue is the identity over this launch's slots (-1 marks pixels outside the frame): no compaction,
-    // no atomic.
-    if (inRange) w.rayq[0][p] = valid ? p : -1;
+    // Bounce 0's queue is the identity over this launch's slots (-1 marks pixels outside the frame; -2 - slot: on the first list, as
+    // k_wf_shade marks such rays): no compaction.
+    if (inRange) w.rayq[0][p] = valid ? (listed ? -2 - p : p) : -1;
     if (blockIdx.x == 0 && threadIdx.x == 0) w.ctr->rayCount[0].v = int(nLocal) * 64;
 }
 

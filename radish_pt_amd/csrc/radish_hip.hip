@@ -463,6 +463,11 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
     auto keep = [&](hipError_t e, const char *what) {
         if (e != hipSuccess && rc == RDH_OK) rc = fail(c, (int)e, "HIP error (%s:%d): %s: %s", __FILE__, __LINE__, what, hipGetErrorString(e));
     };
+    for (int h = 0; h < parts; h++) {  // what a stage's literal-class list may hold: one entry per lane of the trace grid
+        const unsigned waves = traceGrid * 4u;
+        c->wf[h].litCap = (int)(waves * 64u < (unsigned)kWfLitCap ? waves * 64u : (unsigned)kWfLitCap);
+        if (flags & RDH_PT_WF_SMALL_LISTS) c->wf[h].litCap = 4;  // tests: what does not fit stays in the ordinary queues
+    }
     for (int h = 0; h < parts; h++) {
         hipStream_t st = sts[h];
         WaveWorkspace &w = c->wf[h];
@@ -470,11 +475,6 @@ int wavefrontPathTrace(rdh_ctx *c, const PixelMap &pm, float *d_direct, float *d
         const unsigned gridBlk = (((nLocal + 3u) / 4u + 7u) / 8u) * 8u;
         keep(hipMemsetAsync(w.ctr, 0, sizeof(WaveCounters), st), "hipMemsetAsync(wavefront counters)");
         hipLaunchKernelGGL(k_wf_raygen, dim3(gridBlk), dim3(256), 0, st, c->ds, c->cam, pm, w, looper, h, parts);
-    }
-    for (int h = 0; h < parts; h++) {  // what a stage's literal-class list may hold: one entry per lane of the trace grid
-        const unsigned waves = traceGrid * 4u;
-        c->wf[h].litCap = (int)(waves * 64u < (unsigned)kWfLitCap ? waves * 64u : (unsigned)kWfLitCap);
-        if (flags & RDH_PT_WF_SMALL_LISTS) c->wf[h].litCap = 4;  // tests: what does not fit stays in the ordinary queues
     }
     for (int k = 0; k <= maxDepth && rc == RDH_OK; k++) {
         for (int h = 0; h < parts; h++) {  // interleaved issue: stage k of every pipeline before stage k + 1 of any
