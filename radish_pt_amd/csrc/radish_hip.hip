@@ -846,7 +846,10 @@ int rdh_scene_upload(rdh_ctx *c, const rdh_scene_desc *d) {
         int depth = 0;
         c->ds.pairs = nullptr;
         c->ds.treeDepth = 0;
-        if (buildSharedTree(d, S, tree, pairs, depth)) {
+        // (a walker keeps a strip of treeDepth entries per lane in global memory for the deep end of its stack: a degenerate tree — a
+        // chain thousands of levels deep — keeps the threaded walk, which needs no stack)
+        constexpr int kMaxPairDepth = 2048;
+        if (buildSharedTree(d, S, tree, pairs, depth) && depth <= kMaxPairDepth) {
             if ((rc = uploadVec(c, pairs, &c->ds.pairs))) return rc;
             c->ds.treeDepth = depth;
             c->ds.rootLo = make_float4(tree[0].lo_prim.x, tree[0].lo_prim.y, tree[0].lo_prim.z,
