@@ -111,9 +111,11 @@ typedef struct rdh_counters {
 #define RDH_PT_PAIRS 32768u    /* per-lane walks over SIBLING PAIRS (one 64-byte record per inner node, shared by the six orderings: a lane
                                   that enters a node fetches both children and tests both boxes in one round trip; the far child is
                                   re-checked when the walk reaches it) instead of the six threaded arrays; same records, same counters.
-                                  Default: by scene size (>= 100 000 nodes).  rdh_trace_closest / rdh_trace_occluded (with
-                                  RDH_PT_PERSISTENT) return RDH_ERR_UNSUPPORTED when the uploaded arrays are not six orderings of
-                                  one binary tree; the frame entries then walk the threaded arrays */
+                                  Default: on, whenever the six uploaded arrays are orderings of ONE binary tree at most 2 048 levels
+                                  deep (every tree Radish's builder makes is one tree; n coincident triangles make a chain of n - 1
+                                  levels).  Otherwise the threaded arrays are walked: silently by the frame entries, while
+                                  rdh_trace_closest / rdh_trace_occluded (with RDH_PT_PERSISTENT) return RDH_ERR_UNSUPPORTED when
+                                  the flag asks for pairs that do not exist */
 #define RDH_PT_NO_PAIRS 16384u /* never walk the sibling pairs */
 #define RDH_PT_AUTO 65536u     /* rdh_path_trace / rdh_path_trace_gathered*: the library picks the structure by what this launch holds —
                                   the wavefront pipeline with material sort and three sub-frames for a big tree (>= 100 000 nodes) and a

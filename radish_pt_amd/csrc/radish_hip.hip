@@ -531,7 +531,7 @@ int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *
                const int *deferList = nullptr, int slotList = 0, bool pairs = false) {
     const int any = d_occ ? 1 : 0;
     // everything that can fail comes BEFORE the fork, so that no error path leaves the side stream un-joined
-    if (pairs && !c->ds.pairs) return fail(c, RDH_ERR_UNSUPPORTED, "RDH_PT_PAIRS: the uploaded node arrays are not six orderings of one binary tree");
+    if (pairs && !c->ds.pairs) return fail(c, RDH_ERR_UNSUPPORTED, "RDH_PT_PAIRS: the uploaded node arrays are not six orderings of one binary tree, or that tree is more than 2 048 levels deep");
     unsigned &resGrid = pairs ? c->pairGrid[any] : c->walkGrid[any];
     if (resGrid == 0) {
         int perCU = 0, cus = 0;

@@ -936,6 +936,89 @@ def test_mirror_frame_loop_like_runCuda():
         api.State.looper = 0
 
 
+@pytest.mark.parametrize("n_stack,expect_pairs", [(1500, True), (2300, False)])
+def test_chain_shaped_tree_ties_deep_stacks_and_the_threaded_fallback(gpu_ctx, n_stack, expect_pairs):
+    """n coincident triangles: the SAH builder has nothing to split on and returns a CHAIN (one leaf and one inner child per level,
+    n - 1 levels), and every ray that hits one of them hits all of them at the SAME distance — the strict `<` of DevScene::intersect
+    (scene.h:285) decides by visiting order, which differs between the six orderings.  The materials alternate, so a wrong winner
+    shows in the image.  1 500 levels: the sibling-pair walks keep up to that many pending far children per lane when they count
+    (failed far children are stacked too) — an LDS ring of 8 entries, the rest in the global strip (traverse.h, pairPush).  2 300
+    levels is past the depth the strips are sized for (radish_hip.hip, kMaxPairDepth): the scene silently keeps the threaded walk,
+    and asking for pairs by flag is refused.  Either way: hits, images and work counters equal the oracle's."""
+    from radish_pt_amd import api, hostlib, layouts as L, scenes
+
+    torch = _torch()
+    mats = [L.make_material(L.LAMBERTIAN, (0.8, 0.3, 0.2)), L.make_material(L.LAMBERTIAN, (0.2, 0.7, 0.9)),
+            L.make_material(L.METALLIC_WORKFLOW, (0.9, 0.9, 0.9), metallic=0.6, roughness=0.35), L.make_material(L.LIGHT, (7.0, 6.5, 6.0))]
+    tri = np.array([[-1.2, -0.4, 0.1], [1.3, -0.5, -0.2], [0.1, 1.4, 0.3]], np.float32)
+    nrm = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+    nrm = np.tile((nrm / np.linalg.norm(nrm)).astype(np.float32), (3, 1))
+    uv = np.array([[0, 0], [1, 0], [0, 1]], np.float32)
+    floor = np.array([[-3, -0.8, -3], [3, -0.8, -3], [3, -0.8, 3], [-3, -0.8, -3], [3, -0.8, 3], [-3, -0.8, 3]], np.float32)
+    lamp = np.array([[-0.6, 2.4, -0.6], [0.6, 2.4, -0.6], [0.6, 2.4, 0.6], [-0.6, 2.4, -0.6], [0.6, 2.4, 0.6], [-0.6, 2.4, 0.6]], np.float32)  # facing down
+    v = np.concatenate([np.tile(tri, (n_stack, 1)), floor, lamp])
+    n = np.concatenate([np.tile(nrm, (n_stack, 1)), np.tile(np.array([0, 1, 0], np.float32), (6, 1)), np.tile(np.array([0, -1, 0], np.float32), (6, 1))])
+    t = np.tile(uv, (n_stack + 4, 1))
+    ids = np.array([i % 3 for i in range(n_stack)] + [0, 0, 3, 3], np.int32)
+    sd = scenes.SceneData(f"chain{n_stack}", v, n, t, ids, np.array(mats, dtype=L.MATERIAL_DTYPE))
+    gpu_ctx.set_partition(0, 1, 64)
+    gpu_ctx.upload_scene(sd)
+    o = _oracle(sd)
+    # ---- ray batches: closest hit and any hit, every walker, equal counters ----
+    rays = random_rays(1536, seed=41)
+    rays[:, :3] *= 0.6
+    seg = random_segments(1536, seed=43)
+    ref_h = o.trace_closest(rays)
+    st_h = o.stats()
+    o.reset_stats()
+    ref_o = o.trace_occluded(seg)
+    st_o = o.stats()
+    assert 0.1 < (ref_h["primId"] >= 0).mean() and len(set(ref_h["primId"][ref_h["primId"] >= 0] % 3)) >= 2  # ties resolved both ways
+    walkers = [0, api.RDH_PT_PERSISTENT | api.RDH_PT_NO_PAIRS, api.RDH_PT_PERSISTENT] + ([api.RDH_PT_PERSISTENT | api.RDH_PT_PAIRS] if expect_pairs else [])
+    for flags in walkers:
+        d_hits = torch.full((len(rays), 4), 0x7fffffff, dtype=torch.int32, device="cuda")
+        gpu_ctx.counters_reset()
+        gpu_ctx.trace_closest(_dev(rays), d_hits, api.RDH_PT_COUNT | flags)
+        got = d_hits.cpu().numpy().view(L.HIT_DTYPE).reshape(-1)
+        assert np.array_equal(got["primId"], ref_h["primId"]), flags
+        for f in ("u", "v", "t"):
+            assert_bit_equal(got[f], ref_h[f], f"hit.{f} flags={flags}")
+        ct = gpu_ctx.counters()
+        assert ct["nodeVisits"] == st_h["nodeVisits"] and ct["triTests"] == st_h["triTests"], flags
+        gpu_ctx.trace_closest(_dev(rays), d_hits, flags)  # and without the counters (failed far children are not stacked then)
+        assert np.array_equal(d_hits.cpu().numpy().view(L.HIT_DTYPE).reshape(-1)["primId"], ref_h["primId"]), flags
+        d_occ = torch.full((len(seg),), -7, dtype=torch.int32, device="cuda")
+        gpu_ctx.counters_reset()
+        gpu_ctx.trace_occluded(_dev(seg), d_occ, api.RDH_PT_COUNT | flags)
+        assert np.array_equal(d_occ.cpu().numpy(), ref_o), flags
+        ct = gpu_ctx.counters()
+        assert ct["nodeVisits"] == st_o["nodeVisits"] and ct["triTests"] == st_o["triTests"], flags
+    if not expect_pairs:
+        with pytest.raises(api.RadishError):
+            gpu_ctx.trace_closest(_dev(rays), torch.zeros(len(rays), 4, dtype=torch.int32, device="cuda"), api.RDH_PT_PERSISTENT | api.RDH_PT_PAIRS)
+    # ---- whole frames through every structure ----
+    W, H = 48, 32
+    npx = W * H
+    cam = hostlib.make_camera(W, H, eye=(0.2, 0.7, 4.5), rotation=(-90.0, 0.0, 0.0), fovy=19.5)
+    gpu_ctx.set_camera(cam)
+    o.reset_stats()
+    ref_d, ref_i = np.zeros((npx, 3), np.float32), np.zeros((npx, 3), np.float32)
+    o.path_trace(cam, ref_d, ref_i, 0, 5, 4)
+    st = o.stats()
+    for flags in (api.RDH_PT_PERSISTENT, api.RDH_PT_WAVEFRONT | api.RDH_PT_SORT_MATERIAL, api.RDH_PT_WAVEFRONT | api.RDH_PT_WF_SUBFRAMES, api.RDH_PT_AUTO):
+        d, i = torch.zeros(npx, 3, device="cuda"), torch.zeros(npx, 3, device="cuda")
+        gpu_ctx.counters_reset()
+        gpu_ctx.path_trace(d, i, 0, 5, 4, flags | api.RDH_PT_COUNT)
+        assert_bit_equal(d.cpu().numpy(), ref_d, f"chain direct flags={flags}")
+        assert_bit_equal(i.cpu().numpy(), ref_i, f"chain indirect flags={flags}")
+        assert gpu_ctx.counters() == st, flags
+        d.zero_(); i.zero_()
+        gpu_ctx.path_trace(d, i, 0, 5, 4, flags)
+        assert_bit_equal(d.cpu().numpy(), ref_d, f"chain direct flags={flags} (no counters)")
+        assert_bit_equal(i.cpu().numpy(), ref_i, f"chain indirect flags={flags} (no counters)")
+    assert (ref_d > 0).any() and (ref_i > 0).any()
+
+
 @pytest.mark.parametrize("case", ["one_triangle", "no_lights", "only_lights"])
 def test_degenerate_scenes_bit_exact(gpu_ctx, case):
     """Smallest inputs: a single triangle (BVH of one node), a scene without emitters (NEE and RIS have nothing to pick: the
