@@ -119,6 +119,10 @@ RD_DEV float pdfAreaToSolidAngle(float pdf, v3 x, v3 y, v3 ny) {  // :188-192
     v3 yx = x - y;
     return pdf * dot(yx, yx) / absDot(ny, normalize(yx));
 }
+// The same value where the caller already holds v = y - x (= -yx exactly), d2 = dot(v, v) and wi = normalize(v) = v * (1 / sqrt(d2)):
+// dot(yx, yx) is d2 bit for bit (products of equal magnitudes), normalize(yx) is -wi (a product by the same reciprocal) and
+// dot(ny, -wi) is -dot(ny, wi) (rounding to nearest is symmetric), so one dot product, one square root and one reciprocal less.
+RD_DEV float pdfAreaToSolidAngleFrom(float pdf, float d2, v3 ny, v3 wi) { return pdf * d2 / fabs_(dot(ny, wi)); }
 
 // ---- material.h ----
 struct Material {

@@ -117,9 +117,10 @@ RD_DEV float lightPdfUnoccluded(const DScene &s, v3 pos, const LightPick &p, v3 
     v3 posToSampled = p.sampled - pos;
     if (dot(p.normal, posToSampled) > -1e-6f) return INVALID_PDF;  // SCENE_LIGHT_SINGLE_SIDED
     radiance = p.radiance;
-    wi = normalize(posToSampled);
+    const float d2 = dot(posToSampled, posToSampled);
+    wi = posToSampled * rsqrt_exact(d2);  // normalize(posToSampled)
     float power = luminance(radiance) / (p.area * 2.f * PI_F);
-    return pdfAreaToSolidAngle(power * s.sumLightPowerInv, pos, p.sampled, p.normal);
+    return pdfAreaToSolidAngleFrom(power * s.sumLightPowerInv, d2, p.normal, wi);  // pdfAreaToSolidAngle(.., pos, p.sampled, p.normal)
 }
 
 // sampleDirectLightNoVisibility (scene.h:458-492)
@@ -135,10 +136,11 @@ RD_DEV float sampleDirectLightNoVisibility(const DScene &s, v3 pos, v4 r, v3 &ra
     v3 posToSampled = p.sampled - pos;
     if (dot(p.normal, posToSampled) > -1e-6f) return INVALID_PDF;
     radiance = p.radiance;
-    wi = normalize(posToSampled);
-    dist = length(posToSampled);
+    const float d2 = dot(posToSampled, posToSampled);
+    dist = __builtin_sqrtf(d2);            // length(posToSampled)
+    wi = posToSampled * (1.f / dist);      // normalize(posToSampled) = v * (1 / sqrt(dot(v, v)))
     float power = luminance(radiance) / (p.area * 2.f * PI_F);
-    return pdfAreaToSolidAngle(power * s.sumLightPowerInv, pos, p.sampled, p.normal);
+    return pdfAreaToSolidAngleFrom(power * s.sumLightPowerInv, d2, p.normal, wi);  // pdfAreaToSolidAngle(.., pos, p.sampled, p.normal)
 }
 
 }  // namespace rd
