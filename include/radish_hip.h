@@ -117,6 +117,10 @@ typedef struct rdh_counters {
                                   rdh_trace_closest / rdh_trace_occluded (with RDH_PT_PERSISTENT) return RDH_ERR_UNSUPPORTED when
                                   the flag asks for pairs that do not exist */
 #define RDH_PT_NO_PAIRS 16384u /* never walk the sibling pairs */
+#define RDH_PT_NO_PACKETS 8192u /* rdh_gbuffer_render, rdh_restir_direct: primary rays lane by lane (the lane-refill walkers) instead of as
+                                  PACKETS — one 8x8 pixel block per wave, walked through the threaded order together with one uniform
+                                  node load per visit (traverse.h, packetWalk); same records, same counters.  (rdh_path_trace keeps its
+                                  primary rays in trace(0): measured) */
 #define RDH_PT_AUTO 65536u     /* rdh_path_trace / rdh_path_trace_gathered*: the library picks the structure by what this launch holds —
                                   the wavefront pipeline with material sort and three sub-frames for a big tree (>= 100 000 nodes) and a
                                   big share of the frame (>= 12 000 8x8 blocks: a 1080p frame, or half of one), else the persistent kernel

@@ -38,6 +38,7 @@ RDH_PT_RESTIR_FUSED = 1024
 RDH_PT_WF_SUBFRAMES = 2048
 RDH_PT_WF_SMALL_LISTS = 4096
 RDH_PT_NO_PAIRS = 16384
+RDH_PT_NO_PACKETS = 8192
 RDH_PT_PAIRS = 32768
 RDH_PT_AUTO = 65536
 SOBOL_SAMPLE_NUM = 10000  # SobolSampleNum, src/sampler.h:12

@@ -903,6 +903,53 @@ __global__ __launch_bounds__(64, PAIRS && !COUNT ? 4 : 1) void k_gbuffer_persist
     if (COUNT) flushCounters(s.counters, nClosest, 0u, nHits, ws);
 }
 
+// ---- renderGBuffer with the primary rays of an 8x8 block walked as a PACKET (traverse.h, packetWalk) ---------------------------------
+// Centre rays of neighbouring pixels make nearly the same walk (teapots camera: 89 visits per ray, 107 different nodes per block), so
+// a wave takes one block, walks the union once with one uniform node load per visit, and writes its 64 records.  No lane refill,
+// no persistent grid: a wave's work is one short walk.  Same centre ray, same visits, same record per pixel as k_gbuffer.
+template <bool COUNT, bool DEFER>
+__global__ __launch_bounds__(256) void k_gbuffer_packet(DScene s, DCamera cam, DCamera lastCam, PixelMap pm, GBufPtrs gb, const PersistCounters *pc) {
+    const int lane = int(threadIdx.x) & 63;
+    const unsigned blk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (blk >= (unsigned)pm.numBlocks) return;
+    const int end = s.bvhSize;
+    const Pix px = mapPixel(pm, blk, (unsigned)lane);
+    WalkStats ws{0, 0};
+    unsigned nClosest = 0, nHits = 0;
+    const bool deferAll = DEFER && pc->deferCount <= kDeferCap;  // written by k_gbuffer_find_literal, earlier in the stream
+    Ray ray{mk3(0.f), mk3(0.f, 0.f, 1.f)};
+    if (px.valid) ray = gbufPrimaryRay(cam, px.x, px.y);
+    const RaySlab rs = makeRaySlab(ray);
+    const int ord = getMTBVHId(-ray.d);
+    float tmax = 3.402823466e+38f;
+    int hitPrim = -1;
+    v2 hitBary = mk2(0.f, 0.f);
+    const bool traced = px.valid && !(DEFER && raySetAside(rs.cls) && end != 0 && deferAll);  // else: k_gbuffer_literal has this pixel
+    if (traced) nClosest++;
+    unsigned long long lit = __ballot(traced && rs.cls != 0 && end != 0);
+    while (lit) {  // literal-class rays kept here: traced whole by the wave, one after the other
+        const int L = __ffsll((long long)lit) - 1;
+        lit &= lit - 1ull;
+        const NodeRec *nodes = s.nodes[0] + (size_t)readlaneI(ord, L) * (size_t)(end + 1);
+        CoopTrace ct = coopTraceWhole<false>(s, nodes, readlaneRay(rs, L), readlaneF(tmax, L));
+        if (lane == L) {
+            hitPrim = ct.hitPrim;
+            hitBary = ct.bary;
+            tmax = ct.tmax;
+            if (COUNT) {
+                ws.nodes += ct.nodes;
+                ws.tris += ct.tris;
+            }
+        }
+    }
+    packetWalkAll<COUNT>(s, traced && rs.cls == 0 && end != 0, ord, rs, tmax, hitPrim, hitBary, ws);
+    if (traced) {
+        if (hitPrim != -1) nHits++;
+        gbufStore(s, cam, lastCam, gb, px.index, rs, hitPrim, hitBary);
+    }
+    if (COUNT) flushCounters(s.counters, nClosest, 0u, nHits, ws);
+}
+
 // Literal-class primary rays are traced apart, each by a whole 1 024-thread workgroup (wg_trace.h), in a launch that runs
 // BESIDE k_gbuffer_persistent on a second stream: traced in place by one wave, one such ray takes 1.2 ms on the teapots scene,
 // twice the rest of the pass.  The ray's class depends on the camera and the pixel only, so a first tiny kernel lists them;

@@ -227,6 +227,56 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
     if (COUNT) flushCounters(s.counters, ANY ? 0u : nRays, ANY ? nRays : 0u, nHits, ws);
 }
 
+// ---- closest hits of a COHERENT ray list — consecutive rays start side by side, e.g. the primary rays of 8x8 pixel blocks in slot
+// order — one 64-ray chunk per wave, walked as a PACKET (traverse.h, packetWalk): one uniform node load per visit for the whole wave
+// instead of one L1 request per lane.  Same records, same counters as the lane-refill walkers; on rays that do not travel together
+// it is merely slow (a wave then visits the union of 64 unrelated walks), so the caller says when a list is coherent.
+// Literal-class rays: set aside for k_trace_wg_list when the producer listed them (DEFER), else traced whole by the wave, in place.
+template <bool COUNT, bool DEFER>
+__global__ __launch_bounds__(256) void k_walk_packet(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,
+                                                     const int *__restrict__ deferCount, int slotList) {
+    const int lane = int(threadIdx.x) & 63;
+    const long long i = ((long long)blockIdx.x * 4 + (long long)(threadIdx.x >> 6)) * 64 + lane;
+    const int end = s.bvhSize;
+    WalkStats ws{0, 0};
+    unsigned nRays = 0, nHits = 0;
+    const bool deferAll = DEFER && *deferCount <= kWalkDeferCap;
+    const bool have = i < n && (slotList == 0 || rays[6 * i] == rays[6 * i]);  // see k_walk_persistent
+    Ray ray{mk3(0.f), mk3(0.f, 0.f, 1.f)};
+    if (have) ray = Ray{mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5])};
+    const RaySlab rs = makeRaySlab(ray);
+    const int ord = getMTBVHId(-ray.d);
+    float tmax = 3.402823466e+38f;
+    int hitPrim = -1;
+    v2 hitBary = mk2(0.f, 0.f);
+    const bool traced = have && !(DEFER && deferAll && raySetAside(rs.cls) && end != 0);  // else: k_trace_wg_list has this ray
+    if (traced) nRays++;
+    unsigned long long lit = __ballot(traced && rs.cls != 0 && end != 0);
+    while (lit) {
+        const int L = __ffsll((long long)lit) - 1;
+        lit &= lit - 1ull;
+        const NodeRec *nodes = s.nodes[0] + (size_t)readlaneI(ord, L) * (size_t)(end + 1);
+        CoopTrace ct = coopTraceWhole<false>(s, nodes, readlaneRay(rs, L), readlaneF(tmax, L));
+        if (lane == L) {
+            hitPrim = ct.hitPrim;
+            hitBary = ct.bary;
+            tmax = ct.tmax;
+            if (COUNT) {
+                ws.nodes += ct.nodes;
+                ws.tris += ct.tris;
+            }
+        }
+    }
+    packetWalkAll<COUNT>(s, traced && rs.cls == 0 && end != 0, ord, rs, tmax, hitPrim, hitBary, ws);
+    if (traced) {
+        const bool hit = hitPrim != -1;
+        if (hit) nHits++;
+        hits[i] = make_int4(hitPrim, __float_as_int(hit ? hitBary.x : 0.f), __float_as_int(hit ? hitBary.y : 0.f),
+                            __float_as_int(hit ? tmax : 3.402823466e+38f));
+    }
+    if (COUNT) flushCounters(s.counters, nRays, 0u, nHits, ws);
+}
+
 // ---- the same walker over SIBLING PAIRS (DScene::pairs; traverse.h, pairStep) ---------------------------------------------------
 template <bool COUNT, bool ANY, bool DEFER = false>
 __global__ __launch_bounds__(64, COUNT ? 1 : 7) void k_walk_pair(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,

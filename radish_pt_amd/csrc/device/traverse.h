@@ -724,6 +724,64 @@ RD_DEV void pairStep(const PairRec *__restrict__ pairs, int2 *stk, int lane, int
     }
 }
 
+// ---- PACKET walk: the rays of a wave through the threaded order TOGETHER ------------------------------------------------------
+// For rays that start side by side — the primary rays of an 8x8 pixel block — the walks of the 64 lanes overlap almost entirely:
+// measured on the teapots camera (scripts/packet_walk_model.py) a wave's lanes visit 89 nodes each and 107 DIFFERENT nodes between
+// them.  So the wave walks ONE node at a time, n = the smallest node any of its lanes wants next, and only the lanes that want n
+// (p == n) test its box and move on (p = n + 1 on a hit, nextNodeIfMiss on a miss); the others wait at the node they skipped
+// to.  In the threaded pre-order a lane that waits skipped from an ancestor-or-self m of n, and nextNodeIfMiss[m] >= nextNodeIfMiss[n]
+// because subtrees nest, so the next n needs no reduction over lanes: n + 1 if any lane hit, else nextNodeIfMiss[n].  Every lane
+// makes exactly the visits of DevScene::intersect (scene.h:262-301) for its ray, in the same order, against its own closest distance:
+// same hit records, same counters.  What changes is the cost of a visit: the node record is ONE uniform load for the wave instead
+// of 64 lane requests to the vector L1 — the walkers' ceiling does not apply.  Rays of class 0 only (`mine`); the array
+// `nd` is the ordering the participating lanes share (the caller loops over the orderings present in the wave).
+template <bool COUNT>
+RD_DEV void packetWalk(const DScene &s, const NodeRec *__restrict__ nd, bool mine, const RaySlab &rs, float &tmax, int &hitPrim, v2 &hitBary,
+                       WalkStats &ws) {
+    const int end = s.bvhSize;
+    int p = mine ? 0 : end;
+    int n = __ballot(mine) != 0ull ? 0 : end;
+    while (n != end) {
+        const float4 lo = nd[n].lo_prim, hi = nd[n].hi_next;  // a uniform address
+        const int prim = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w)), nxt = __builtin_amdgcn_readfirstlane(__float_as_int(hi.w));
+        const bool act = p == n;
+        bool hit = false;
+        if (act) {
+            float boundDist;
+            if (COUNT) ws.nodes++;
+            hit = aabbFast(lo, hi, rs, boundDist) && boundDist < tmax;
+            p = hit ? n + 1 : nxt;
+        }
+        const bool any = __ballot(hit) != 0ull;
+        if (prim >= 0 && any) {  // a leaf some lanes enter: their triangle test, now (scene.h:281-292)
+            if (hit) {
+                const TriVerts tv = loadTri(s.tris, prim);
+                float dist;
+                v2 bary;
+                if (COUNT) ws.tris++;
+                if (intersectTriangle(rs, tv.a, tv.b, tv.c, bary, dist) && dist < tmax) {
+                    hitPrim = prim;
+                    tmax = dist;
+                    hitBary = bary;
+                }
+            }
+        }
+        n = any ? n + 1 : nxt;
+    }
+}
+// The packet walks of a wave whose lanes hold rays of possibly different orderings (a block of primary rays: one, rarely two or three).
+template <bool COUNT>
+RD_DEV void packetWalkAll(const DScene &s, bool mine, int ord, const RaySlab &rs, float &tmax, int &hitPrim, v2 &hitBary, WalkStats &ws) {
+    unsigned long long todo = __ballot(mine);
+    while (todo) {
+        const int L = __ffsll((long long)todo) - 1;
+        const int q = __builtin_amdgcn_readlane(ord, L);
+        const bool now = mine && ord == q;
+        todo &= ~__ballot(now);
+        packetWalk<COUNT>(s, s.nodes[0] + (size_t)q * (size_t)(s.bvhSize + 1), now, rs, tmax, hitPrim, hitBary, ws);
+    }
+}
+
 // Wave-level reduction of the per-lane walk statistics, then one atomic per counter per wave.
 RD_DEV unsigned long long waveSum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

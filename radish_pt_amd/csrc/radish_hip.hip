@@ -34,7 +34,11 @@ struct rdh_ctx {
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evStop = nullptr;
-    hipStream_t sideStream = nullptr;  // k_gbuffer_literal runs here, beside k_gbuffer_persistent
+    hipStream_t sideStream = nullptr;  // the wavefront path's second pipeline, k_persist_schedule
+    hipStream_t litStream = nullptr;   // the workgroup-per-ray launches for literal-class rays (k_gbuffer_literal, k_trace_wg_list), beside the
+                                       // kernel that walks everything else: the side stream.  RADISH_LIT_PRIORITY=1 (experiments): a high-
+                                       // priority stream of its own — those launches then end earlier, frames do not, and the extra
+                                       // hardware queue cost the three-stream wavefront path 4 % (profiles/r03_za_*, r03_zg_*)
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     bool timed = false;
     std::string err;
@@ -320,6 +324,12 @@ bool usePairs(const rdh_ctx *c, uint32_t flags) {
     return c->ds.bvhSize >= kPairMinNodes;
 }
 
+// Primary rays as wave packets (traverse.h, packetWalk)?  RADISH_PACKETS=0 in the environment switches them off (experiments).
+bool usePackets(uint32_t flags) {
+    static const int env = getenv("RADISH_PACKETS") ? atoi(getenv("RADISH_PACKETS")) : 1;
+    return env != 0 && !(flags & RDH_PT_NO_PACKETS);
+}
+
 // Grid for "4 waves per workgroup, one 8x8 block per wave", padded to a multiple of 8 workgroups (xcdSwizzle).
 unsigned gridFor(const PixelMap &pm) {
     unsigned work = (unsigned)(pm.numBlocks + 3) / 4;
@@ -528,8 +538,9 @@ int ensureStackOverflow(rdh_ctx *c, size_t ints) {
 // deferCount / deferList (ReSTIR's lists): literal-class rays have been listed by the producer of `d_rays`; they are traced one
 // per workgroup on the side stream beside the walker, which skips them; the stream waits for both before it goes on.
 int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *d_occ, bool count, const int *deferCount = nullptr,
-               const int *deferList = nullptr, int slotList = 0, bool pairs = false) {
+               const int *deferList = nullptr, int slotList = 0, bool pairs = false, bool packets = false) {
     const int any = d_occ ? 1 : 0;
+    packets = packets && !any && n > 0 && (n + 255) / 256 <= 0x7fffffffll;  // closest hits of a list the caller calls coherent
     // everything that can fail comes BEFORE the fork, so that no error path leaves the side stream un-joined
     if (pairs && !c->ds.pairs) return fail(c, RDH_ERR_UNSUPPORTED, "RDH_PT_PAIRS: the uploaded node arrays are not six orderings of one binary tree, or that tree is more than 2 048 levels deep");
     unsigned &resGrid = pairs ? c->pairGrid[any] : c->walkGrid[any];
@@ -556,12 +567,12 @@ int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *
     hipError_t ew = hipSuccess;
     if (deferCount) {
         HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
-        ew = hipStreamWaitEvent(c->sideStream, c->evFork, 0);
+        ew = hipStreamWaitEvent(c->litStream, c->evFork, 0);
         if (ew == hipSuccess) {
-            if (any && count) hipLaunchKernelGGL((k_trace_wg_list<true, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
-            else if (any) hipLaunchKernelGGL((k_trace_wg_list<false, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
-            else if (count) hipLaunchKernelGGL((k_trace_wg_list<true, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
-            else hipLaunchKernelGGL((k_trace_wg_list<false, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+            if (any && count) hipLaunchKernelGGL((k_trace_wg_list<true, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->litStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+            else if (any) hipLaunchKernelGGL((k_trace_wg_list<false, true>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->litStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+            else if (count) hipLaunchKernelGGL((k_trace_wg_list<true, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->litStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
+            else hipLaunchKernelGGL((k_trace_wg_list<false, false>), dim3(kWalkDeferCap), dim3(kWgTraceThreads), 0, c->litStream, c->ds, d_rays, deferList, deferCount, d_hits, d_occ);
         }
     }
 #define RD_LAUNCH_WALK(CNT, ANYHIT, DEF)                                                                                                      \
@@ -573,15 +584,27 @@ int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *
             hipLaunchKernelGGL((k_walk_persistent<CNT, ANYHIT, DEF>), dim3(grid), dim3(64), 0, c->stream, c->ds, d_rays, n, d_hits, d_occ,    \
                                c->dPersist, deferCount, slotList);                                                                           \
     } while (0)
-    if (deferCount) {
+    if (packets) {  // one 64-ray chunk per wave, walked as a packet (kernels_walk.h, k_walk_packet)
+        const unsigned pgrid = (unsigned)((n + 255) / 256);
+        if (deferCount && count) hipLaunchKernelGGL((k_walk_packet<true, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList);
+        else if (deferCount) hipLaunchKernelGGL((k_walk_packet<false, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList);
+        else if (count) hipLaunchKernelGGL((k_walk_packet<true, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList);
+        else hipLaunchKernelGGL((k_walk_packet<false, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList);
+        if (deferCount) {
+            hipError_t e1 = hipEventRecord(c->evJoin, c->litStream);
+            hipError_t e2 = hipStreamWaitEvent(c->stream, c->evJoin, 0);
+            if (e1 != hipSuccess || e2 != hipSuccess) hipStreamSynchronize(c->litStream);
+            HIP_TRY(c, ew);
+        }
+    } else if (deferCount) {
         if (any && count) RD_LAUNCH_WALK(true, true, true);
         else if (any) RD_LAUNCH_WALK(false, true, true);
         else if (count) RD_LAUNCH_WALK(true, false, true);
         else RD_LAUNCH_WALK(false, false, true);
         // the join is unconditional: whatever failed above, the stream goes on only after the side stream's work
-        hipError_t e1 = hipEventRecord(c->evJoin, c->sideStream);
+        hipError_t e1 = hipEventRecord(c->evJoin, c->litStream);
         hipError_t e2 = hipStreamWaitEvent(c->stream, c->evJoin, 0);
-        if (e1 != hipSuccess || e2 != hipSuccess) hipStreamSynchronize(c->sideStream);
+        if (e1 != hipSuccess || e2 != hipSuccess) hipStreamSynchronize(c->litStream);
         HIP_TRY(c, ew);
     } else {
         if (any && count) RD_LAUNCH_WALK(true, true, false);
@@ -631,6 +654,16 @@ int rdh_create(rdh_ctx **out, int device) {
         return RDH_ERR_NO_DEVICE;
     }
     c->stream = c->ownStream;
+    c->litStream = c->sideStream;
+    {
+        const char *e = getenv("RADISH_LIT_PRIORITY");
+        int least = 0, greatest = 0;
+        if (e && atoi(e) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least) {
+            hipStream_t hs = nullptr;
+            if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, greatest) == hipSuccess) c->litStream = hs;
+            else (void)hipGetLastError();
+        }
+    }
     // cleared on the context's own (non-blocking) stream: a null-stream memset is not ordered against it
     if (hipMemsetAsync(c->dCounters, 0, sizeof(Counters), c->stream) != hipSuccess ||
         hipMemsetAsync(c->dPersist, 0, sizeof(PersistCounters), c->stream) != hipSuccess ||
@@ -668,6 +701,10 @@ void rdh_destroy(rdh_ctx *c) {
     for (int h = 0; h < 3; h++)
         if (c->wfTreeOvf[h]) hipFree(c->wfTreeOvf[h]);
     if (c->sideStream) hipStreamSynchronize(c->sideStream);
+    if (c->litStream && c->litStream != c->sideStream) {
+        hipStreamSynchronize(c->litStream);
+        hipStreamDestroy(c->litStream);
+    }
     for (int k = 0; k < 2; k++) {
         if (c->blockCost[k]) hipFree(c->blockCost[k]);
         if (c->blockOrder[k]) hipFree(c->blockOrder[k]);
@@ -709,6 +746,7 @@ int rdh_set_stream(rdh_ctx *c, void *s) {
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->sideStream) HIP_TRY(c, hipStreamSynchronize(c->sideStream));
+        if (c->litStream != c->sideStream) HIP_TRY(c, hipStreamSynchronize(c->litStream));
         if (c->wfStream) HIP_TRY(c, hipStreamSynchronize(c->wfStream));
         if (c->commStream) HIP_TRY(c, hipStreamSynchronize(c->commStream));
         c->gbufPending = c->resvPending = false;
@@ -1141,12 +1179,21 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
         const unsigned pixels = (unsigned)(c->cam.resx * c->cam.resy);
         hipLaunchKernelGGL(k_gbuffer_find_literal, dim3((pixels + 255u) / 256u), dim3(256), 0, c->stream, c->ds, c->cam, pm, c->dPersist);
         HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evFork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->litStream, c->evFork, 0));
         if (count)
-            hipLaunchKernelGGL(k_gbuffer_literal<true>, dim3(kDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, c->cam, last, p, c->dPersist);
+            hipLaunchKernelGGL(k_gbuffer_literal<true>, dim3(kDeferCap), dim3(kWgTraceThreads), 0, c->litStream, c->ds, c->cam, last, p, c->dPersist);
         else
-            hipLaunchKernelGGL(k_gbuffer_literal<false>, dim3(kDeferCap), dim3(kWgTraceThreads), 0, c->sideStream, c->ds, c->cam, last, p, c->dPersist);
-        HIP_TRY(c, hipEventRecord(c->evJoin, c->sideStream));
+            hipLaunchKernelGGL(k_gbuffer_literal<false>, dim3(kDeferCap), dim3(kWgTraceThreads), 0, c->litStream, c->ds, c->cam, last, p, c->dPersist);
+        HIP_TRY(c, hipEventRecord(c->evJoin, c->litStream));
+    }
+    if (usePackets(flags)) {  // one 8x8 block per wave, its 64 centre rays walked as a packet (kernels_persist.h, k_gbuffer_packet)
+        const unsigned pgrid = ((unsigned)pm.numBlocks + 3u) / 4u;
+        if (count && defer) hipLaunchKernelGGL((k_gbuffer_packet<true, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+        else if (count) hipLaunchKernelGGL((k_gbuffer_packet<true, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+        else if (defer) hipLaunchKernelGGL((k_gbuffer_packet<false, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+        else hipLaunchKernelGGL((k_gbuffer_packet<false, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+        if (defer) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evJoin, 0));
+        return timeEnd(c, "renderGBuffer");
     }
 #define RD_LAUNCH_GBUF(CNT, DEF)                                                                                                             \
     do {                                                                                                                                     \
@@ -1290,7 +1337,7 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
         hipLaunchKernelGGL(k_restir_raygen, dim3(gridBlk), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, apronBlocks, sp.rays,
                            sp.deferCount, sp.deferList);
         const bool pairs = usePairs(c, flags);
-        if ((rc = launchWalk(c, sp.rays, slots, sp.hits, nullptr, count, defer ? sp.deferCount : nullptr, sp.deferList, 1, pairs))) return rc;
+        if ((rc = launchWalk(c, sp.rays, slots, sp.hits, nullptr, count, defer ? sp.deferCount : nullptr, sp.deferList, 1, pairs, usePackets(flags)))) return rc;
         const int nLights = c->ds.lightSamplerLength - (c->ds.envSamplerLength != 0 ? 1 : 0);
         const size_t ldsBytes = (size_t)nLights * sizeof(LightPre) + (size_t)c->ds.lightSamplerLength * sizeof(AliasRec);
         const bool staged = nLights > 0 && ldsBytes <= kRisLdsBytes;

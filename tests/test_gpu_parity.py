@@ -313,6 +313,8 @@ def test_path_trace_direct_bit_exact(cornell_gpu, cornell_small):
 @pytest.mark.parametrize("reuse", [0, 1, 2, 3])
 @pytest.mark.parametrize("faithful", [1, 0])
 def test_restir_sequence_bit_exact(gpu_ctx, reuse, faithful):
+    """(Pass 1's primary rays: walked as packets — the default — when `faithful`, lane by lane otherwise, so both walkers of the
+    jittered primary ray go through every reuse mode.)"""
     from oracle import pyoracle
     from radish_pt_amd import api, hostlib, layouts as L, scenes
 
@@ -351,7 +353,7 @@ def test_restir_sequence_bit_exact(gpu_ctx, reuse, faithful):
         gpu_ctx.set_camera(cam)
         gpu_ctx.counters_reset()
         gpu_ctx.restir_direct(img, 0, 40 + f, gb.c_struct(cam), reuse, faithful_ris=faithful,
-                              flags=api.RDH_PT_COUNT)
+                              flags=api.RDH_PT_COUNT | (0 if faithful else api.RDH_PT_NO_PACKETS))
         got = img.cpu().numpy()
         assert _frac_outside(got, ref_img) == 0.0
         assert_bit_equal(got, ref_img, f"ReSTIR frame {f} reuse={reuse}")
@@ -366,10 +368,11 @@ def test_restir_sequence_bit_exact(gpu_ctx, reuse, faithful):
     gpu_ctx.restir_free()
 
 
-@pytest.mark.parametrize("kernel", ["persistent", "one_lane_per_pixel"])
+@pytest.mark.parametrize("kernel", ["packets", "persistent", "one_lane_per_pixel"])
 def test_gbuffer_kernels_bit_exact(gpu_ctx, kernel):
-    """renderGBuffer (gBuffer.cu:3-76): the persistent lane-refill kernel and the one-lane-per-pixel kernel both equal the
-    oracle plane by plane, with equal work counters, at a size that is not a multiple of the 8x8 block."""
+    """renderGBuffer (gBuffer.cu:3-76): the packet kernel (one 8x8 block per wave, its rays walked together: the default), the
+    persistent lane-refill kernel and the one-lane-per-pixel kernel all equal the oracle plane by plane, with equal work
+    counters, at a size that is not a multiple of the 8x8 block."""
     from oracle import pyoracle
     from radish_pt_amd import api, hostlib, scenes
 
@@ -382,7 +385,7 @@ def test_gbuffer_kernels_bit_exact(gpu_ctx, kernel):
     gb_ref = pyoracle.GBufferHost(W, H)
     gb = api.GBuffer()
     gb.create(W, H)
-    flags = api.RDH_PT_COUNT | (api.RDH_PT_MEGA_GBUFFER if kernel == "one_lane_per_pixel" else 0)
+    flags = api.RDH_PT_COUNT | {"one_lane_per_pixel": api.RDH_PT_MEGA_GBUFFER, "persistent": api.RDH_PT_NO_PACKETS, "packets": 0}[kernel]
     for cam in cams:
         o.stats_reset() if hasattr(o, "stats_reset") else None
         before = o.stats()
@@ -421,7 +424,8 @@ def _count_literal_primary_rays(cam):
 
 @pytest.mark.parametrize("size", [(151, 91), (301, 45)])
 @pytest.mark.parametrize("defer", [True, False])
-def test_gbuffer_literal_rays_bit_exact(gpu_ctx, defer, size):
+@pytest.mark.parametrize("packets", [True, False])
+def test_gbuffer_literal_rays_bit_exact(gpu_ctx, defer, size, packets):
     """Primary rays with an axis-parallel direction component take the box test's special cases (bvh.h:138-148) and visit
     a large part of the tree.  rdh_gbuffer_render lists them for k_gbuffer_literal, where a whole workgroup traces
     each (wg_trace.h) — unless the frame has more than 256 of them (the second size) or RDH_PT_NO_DEFER is given: then one wave
@@ -441,7 +445,7 @@ def test_gbuffer_literal_rays_bit_exact(gpu_ctx, defer, size):
     gb_ref = pyoracle.GBufferHost(W, H)
     gb = api.GBuffer()
     gb.create(W, H)
-    flags = api.RDH_PT_COUNT | (0 if defer else api.RDH_PT_NO_DEFER)
+    flags = api.RDH_PT_COUNT | (0 if defer else api.RDH_PT_NO_DEFER) | (0 if packets else api.RDH_PT_NO_PACKETS)
     for cam in cams:
         before = o.stats()
         o.gbuffer_render(cam, gb_ref)

@@ -59,6 +59,8 @@ def test_hot_kernels_stay_under_their_occupancy_steps():
         ("_ZN2rd11k_walk_pairILb0ELb0E", 80, 6, 0),
         ("_ZN2rd12k_restir_risILb1E", 128, 4, 0),
         ("_ZN2rd20k_gbuffer_persistentILb0E", 128, 4, 0),
+        ("_ZN2rd13k_walk_packetILb0E", 64, 8, 0),      # packet walks: the walk itself needs few registers; many waves hide the
+        ("_ZN2rd16k_gbuffer_packetILb0E", 72, 7, 0),   # scalar-load latency of a wave's one-node-at-a-time chain
     ]
     for prefix, vgprs, waves, scratch in budgets:
         for name, r in one(prefix).items():
