@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void k_restir_pass2(DScene s, PixelMap pm, int
 // Pass 1 as five launches (the default since round 2): the two WALKS leave the pixel kernel.
 //
 //   k_restir_raygen   jittered primary ray of every pixel of the launch domain           -> ray list    (24 B / slot)
-//   k_walk_persistent closest hit of the list (lane refill, 8 waves per SIMD)            -> hit records (16 B)
+//   k_walk_packet     closest hit of the list, one 8x8 block per wave as a PACKET        -> hit records (16 B)
+//                     (traverse.h, packetWalk; RDH_PT_NO_PACKETS: the lane-refill walker k_walk_pair / k_walk_persistent)
 //   k_restir_ris      surface fetch, 32-candidate RIS from an LDS-resident light table   -> raw reservoir, shadow segment, state
 //   k_walk_persistent any hit of the shadow segments                                     -> occlusion flags (4 B)
 //   k_restir_resolve  visibility, temporal merge, the two reservoir stores (restir.cu:158-187)
