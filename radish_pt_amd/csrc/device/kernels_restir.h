@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_restir_pass2(DScene s, PixelMap pm, int
 //   k_walk_packet     closest hit of the list, one 8x8 block per wave as a PACKET        -> hit records (16 B)
 //                     (traverse.h, packetWalk; RDH_PT_NO_PACKETS: the lane-refill walker k_walk_pair / k_walk_persistent)
 //   k_restir_ris      surface fetch, 32-candidate RIS from an LDS-resident light table   -> raw reservoir, shadow segment, state
-//   k_walk_persistent any hit of the shadow segments                                     -> occlusion flags (4 B)
+//   k_walk_pair       any hit of the shadow segments (lane refill, sibling pairs)        -> occlusion flags (4 B)
 //   k_restir_resolve  visibility, temporal merge, the two reservoir stores (restir.cu:158-187)
 //
 // In the fused kernel (k_restir_pass1 above, still there behind RDH_PT_RESTIR_FUSED) a pixel keeps its lane for the whole

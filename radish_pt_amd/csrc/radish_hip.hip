@@ -558,12 +558,12 @@ int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *
     if (resident < 8u) resident = 8u;
     const unsigned grid = chunks < resident ? (unsigned)chunks : resident;
     const int ovfDepth = c->ds.treeDepth + 1;  // entry numbers (traverse.h, pairPush)
-    if (pairs) {
+    if (pairs && !packets) {
         int rc = ensureStackOverflow(c, (size_t)resGrid * 64 * (size_t)ovfDepth * 2);
         if (rc) return rc;
     }
     int2 *const ovf = reinterpret_cast<int2 *>(c->treeOvf);
-    HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));
+    if (!packets) HIP_TRY(c, hipMemsetAsync(c->dPersist, 0, offsetof(PersistCounters, deferred), c->stream));  // the walkers' chunk counter
     hipError_t ew = hipSuccess;
     if (deferCount) {
         HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
