@@ -1,15 +1,14 @@
 #!/bin/bash
-# scratch runner (round 3): final check of the tree — GPU suite, smoke, restir workload, default bench
+# scratch runner (round 3): two-rank rehearsal of both bench workloads on ONE GPU (gloo instead of RCCL, both ranks on device 0)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03zp; mkdir -p $OUT; cd $R
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03zq; mkdir -p $OUT; cd $R
 say() { echo "$(date +%T) $*" | tee -a $OUT/progress.log; }
-say "[0] gpu tests"; timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; rc=$?; say "   rc=$rc $(tail -1 $OUT/gpu_tests.log)"
-[ $rc -ne 0 ] && { tail -40 $OUT/gpu_tests.log; exit 1; }
-say "[1] smoke"; timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee -a $OUT/progress.log
-say "[2] restir workload"; timeout -k 10 200 python3 bench.py --workload restir --steps 16 > $OUT/bench_restir.json 2> $OUT/bench_restir.err; say "   rc=$?"
-python3 -c "import json;d=json.loads(open('$OUT/bench_restir.json').read().strip().splitlines()[-1]);print('   ms_per_step',d['ms_per_step'],d['value'])" | tee -a $OUT/progress.log
-say "[3] default bench"; timeout -k 10 500 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; say "   rc=$?"
-python3 -c "
-import json;d=json.loads(open('$OUT/bench_default.json').read().strip().splitlines()[-1]);c=d['configs']
-print('   headline',d['ms_per_step'],d['value'],d['roofline']['frac'],d['parity_check']['bit_exact'],'pipelined',d['pipelined']['ms_per_step'],'cfg2',c['2']['ms_per_step'],'cfg4',c['4']['ms_per_step'],c['4']['ms_per_step_host_blocking'],'cfg5',c['5_scene_one_gpu']['ms_per_step'])" | tee -a $OUT/progress.log
+export RADISH_FORCE_DEVICE=0 RADISH_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
+for wl in pathtrace restir; do
+  say "[$wl] 2 ranks"
+  timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 4 --warmup 2 --workload $wl --no-cpu-baseline > $OUT/bench_${wl}_2rank.json 2> $OUT/bench_${wl}_2rank.err; say "   rc=$?"
+  tail -1 $OUT/bench_${wl}_2rank.json | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('   ', d['n_gpus'], d['ms_per_step'], d['value'], d.get('parity_check'))" | tee -a $OUT/progress.log
+done
 say done
