@@ -1,14 +1,16 @@
 #!/bin/bash
-# scratch runner (round 3): two-rank rehearsal of both bench workloads on ONE GPU (gloo instead of RCCL, both ranks on device 0)
+# scratch runner (round 3): experiment — the G-buffer pass launched beside ReSTIR's shadow walk (RADISH_GBUFFER_INSIDE=1)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03zq; mkdir -p $OUT; cd $R
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03zr; mkdir -p $OUT; cd $R
 say() { echo "$(date +%T) $*" | tee -a $OUT/progress.log; }
-export RADISH_FORCE_DEVICE=0 RADISH_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
-for wl in pathtrace restir; do
-  say "[$wl] 2 ranks"
-  timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 4 --warmup 2 --workload $wl --no-cpu-baseline > $OUT/bench_${wl}_2rank.json 2> $OUT/bench_${wl}_2rank.err; say "   rc=$?"
-  tail -1 $OUT/bench_${wl}_2rank.json | python3 -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print('   ', d['n_gpus'], d['ms_per_step'], d['value'], d.get('parity_check'))" | tee -a $OUT/progress.log
+for v in 0 1; do
+  RADISH_GBUFFER_INSIDE=$v timeout -k 10 200 python3 bench.py --workload restir --steps 16 > $OUT/bench_restir_$v.json 2> $OUT/bench_restir_$v.err; say "   inside=$v rc=$?"
+  python3 -c "import json;d=json.loads(open('$OUT/bench_restir_$v.json').read().strip().splitlines()[-1]);print('   inside=$v ms_per_step',d['ms_per_step'],d['value'])" | tee -a $OUT/progress.log
 done
+say "default bench sub-record 4 with inside=1 (parity sample)"
+RADISH_GBUFFER_INSIDE=1 timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-pipelined --no-traversal-only > $OUT/bench_default_1.json 2> $OUT/bench_default_1.err; say "   rc=$?"
+python3 -c "
+import json;d=json.loads(open('$OUT/bench_default_1.json').read().strip().splitlines()[-1]);c=d['configs']['4']
+print('   cfg4',c['ms_per_step'],c['ms_per_step_host_blocking'],c['parity_sample_ok'])" | tee -a $OUT/progress.log
+say "kernel trace"; RADISH_GBUFFER_INSIDE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_restir -- python3 scripts/pmc_frames.py teapots_lights restir 1920 1080 8 > $OUT/trace_restir.log 2>&1; say "   rc=$?"
 say done
