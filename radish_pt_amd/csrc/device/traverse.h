@@ -745,8 +745,16 @@ RD_DEV void packetWalk(const DScene &s, const NodeRec *__restrict__ nd, bool min
     // (Requesting the two candidates for the next step — n + 1, and the skip target once record n is here — while the lanes test box
     // n was measured: k_gbuffer_packet 389 -> 469 us, k_walk_packet 351 -> 420 us.  Three scalar loads per visit instead of one cost
     // more than the latency they hide: eight waves per SIMD hide it already.)
+    // (constant address space: the records are read-only for the launch, and a uniform load from it is a scalar load whatever the
+    // kernel has stored before the walk — without it the compiler falls back to four VECTOR loads per visit as soon as a store
+    // precedes the loop.  A resident grid striding over the blocks, which this makes possible, was measured: k_walk_packet 338 ->
+    // 428-492 us at 4 096 / 2 048 / 1 024 workgroups; the one-shot grid balances itself.)
+    typedef float rawFloat4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(4))) const rawFloat4 ConstFloat4;
+    ConstFloat4 *const ndc = (ConstFloat4 *)nd;  // record n = vectors 2 n (lo_prim) and 2 n + 1 (hi_next)
     while (n != end) {
-        const float4 lo = nd[n].lo_prim, hi = nd[n].hi_next;  // a uniform address: one scalar load for the wave
+        const rawFloat4 lo4 = ndc[2 * (size_t)n], hi4 = ndc[2 * (size_t)n + 1];  // a uniform address: one scalar load for the wave
+        const float4 lo = make_float4(lo4.x, lo4.y, lo4.z, lo4.w), hi = make_float4(hi4.x, hi4.y, hi4.z, hi4.w);
         const int prim = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w)), nxt = __builtin_amdgcn_readfirstlane(__float_as_int(hi.w));
         const bool act = p == n;
         bool hit = false;
