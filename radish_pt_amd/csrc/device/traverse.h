@@ -735,6 +735,10 @@ RD_DEV void pairStep(const PairRec *__restrict__ pairs, int2 *stk, int lane, int
 // same hit records, same counters.  What changes is the cost of a visit: the node record is ONE uniform load for the wave instead
 // of 64 lane requests to the vector L1 — the walkers' ceiling does not apply.  Rays of class 0 only (`mine`); the array
 // `nd` is the ordering the participating lanes share (the caller loops over the orderings present in the wave).
+#ifndef RD_PACKET_BUDGET
+#define RD_PACKET_BUDGET 256  // 96 … 384 measured: k_gbuffer_packet 377 / 365 / 367 / 351 / 355 us, k_walk_packet 338 / 334 / 337 / 326 / 325 (384 without a budget)
+#endif
+constexpr int kPacketBudget = RD_PACKET_BUDGET;  // visits a wave makes as a packet before its lanes part (see the end of packetWalk)
 template <bool COUNT>
 RD_DEV void packetWalk(const DScene &s, const NodeRec *__restrict__ nd, bool mine, const RaySlab &rs, float &tmax, int &hitPrim, v2 &hitBary,
                        WalkStats &ws) {
@@ -742,6 +746,7 @@ RD_DEV void packetWalk(const DScene &s, const NodeRec *__restrict__ nd, bool min
     const RaySlabPk rp = packSlab(rs);  // the slab test on register pairs (aabbFastPk: the bits of aabbFast)
     int p = mine ? 0 : end;
     int n = __ballot(mine) != 0ull ? 0 : end;
+    int budget = kPacketBudget;
     // (Requesting the two candidates for the next step — n + 1, and the skip target once record n is here — while the lanes test box
     // n was measured: k_gbuffer_packet 389 -> 469 us, k_walk_packet 351 -> 420 us.  Three scalar loads per visit instead of one cost
     // more than the latency they hide: eight waves per SIMD hide it already.)
@@ -779,6 +784,36 @@ RD_DEV void packetWalk(const DScene &s, const NodeRec *__restrict__ nd, bool min
             }
         }
         n = any ? n + 1 : nxt;
+        if (--budget == 0) break;
+    }
+    // A block on a silhouette holds groups of rays that walk different subtrees, and as a packet the wave walks them one after the
+    // other: the union it visits is 107 nodes on average but up to 1 300 (scripts/packet_walk_model.py), and that ONE wave then lasts as
+    // long as the whole launch.  After kPacketBudget visits the lanes that are not done go on EACH ON ITS OWN — node p, own closest
+    // distance, own hit: the threaded walk needs no other state — with one record fetch per lane and step, which costs a ray at most
+    // its own ~90 visits however far the packet's rays have parted.
+    while (__ballot(p != end) != 0ull) {
+        if (p != end) {
+            const float4 lo = nd[p].lo_prim, hi = nd[p].hi_next;
+            float boundDist;
+            if (COUNT) ws.nodes++;
+            if (aabbFastPk(lo, hi, rp, boundDist) && boundDist < tmax) {
+                const int prim = __float_as_int(lo.w);
+                if (prim >= 0) {
+                    const TriVerts tv = loadTri(s.tris, prim);
+                    float dist;
+                    v2 bary;
+                    if (COUNT) ws.tris++;
+                    if (intersectTriangle(rs, tv.a, tv.b, tv.c, bary, dist) && dist < tmax) {
+                        hitPrim = prim;
+                        tmax = dist;
+                        hitBary = bary;
+                    }
+                }
+                p++;
+            } else {
+                p = __float_as_int(hi.w);
+            }
+        }
     }
 }
 // The packet walks of a wave whose lanes hold rays of possibly different orderings (a block of primary rays: one, rarely two or three).

@@ -39,8 +39,10 @@ def _sequential(nodes, boxes, verts, o, d, inv):
     return hit, tmax, visited, tested
 
 
-def _packet(nodes, boxes, verts, rays):
-    """packetWalk for the lanes `rays` = [(o, d, inv)]; returns per lane (hit, distance, visited, tested) and the wave's visit count."""
+def _packet(nodes, boxes, verts, rays, budget=10 ** 9):
+    """packetWalk for the lanes `rays` = [(o, d, inv)]; returns per lane (hit, distance, visited, tested) and the wave's visit count.
+    After `budget` visits as a packet the lanes that are not done go on each on its own, from its own node with its own closest distance
+    (the device does the same after kPacketBudget visits: a block whose rays have parted must not keep one wave for the whole launch)."""
     prim_of, box_of, nxt = nodes["primitiveId"], nodes["boundingBoxId"], nodes["nextNodeIfMiss"]
     end = len(nodes)
     L = len(rays)
@@ -73,12 +75,32 @@ def _packet(nodes, boxes, verts, rays):
             else:
                 p[i] = int(nxt[n])
         n = n + 1 if any_hit else int(nxt[n])  # no reduction over the lanes that wait
+        if wave_visits == budget:
+            break
+    for i in range(L):  # what is left of every lane's walk, lane by lane: the state is (node, closest distance, hit) and nothing else
+        o, d, inv = rays[i]
+        while p[i] != end:
+            m = p[i]
+            visited[i].append(m)
+            b = boxes[box_of[m]]
+            ok, t = _box_test(b[:3], b[3:], o, inv)
+            if ok and t < tmax[i]:
+                q = prim_of[m]
+                if q >= 0:
+                    tested[i].append(int(q))
+                    th, dist = _tri_test(o, d, *verts[3 * q:3 * q + 3])
+                    if th and dist < tmax[i]:
+                        hit[i], tmax[i] = int(q), dist
+                p[i] = m + 1
+            else:
+                p[i] = int(nxt[m])
     assert all(x == end for x in p)
     return [(hit[i], tmax[i], visited[i], tested[i]) for i in range(L)], wave_visits
 
 
+@pytest.mark.parametrize("budget", [10 ** 9, 7])
 @pytest.mark.parametrize("coherent", [True, False])
-def test_packet_walk_makes_every_lanes_own_walk(coherent):
+def test_packet_walk_makes_every_lanes_own_walk(coherent, budget):
     from radish_pt_amd import scenes
 
     sd = scenes.tiny(n_tris=48, seed=5)
@@ -107,7 +129,7 @@ def test_packet_walk_makes_every_lanes_own_walk(coherent):
         for r in rays:
             by_order.setdefault(_ordering(r[1]), []).append(r)
         for k, lanes in by_order.items():  # packetWalkAll: ordering by ordering
-            got, wv = _packet(sd.nodes[k], boxes, verts, lanes)
+            got, wv = _packet(sd.nodes[k], boxes, verts, lanes, budget)
             for (o, d, inv), g in zip(lanes, got):
                 ref = _sequential(sd.nodes[k], boxes, verts, o, d, inv)
                 assert g == ref
@@ -116,5 +138,5 @@ def test_packet_walk_makes_every_lanes_own_walk(coherent):
             packets += 1
             wave_visits += wv
     assert hits > 30 and packets >= 12
-    if coherent:  # neighbouring rays: the union of 64 walks is not much more than one walk
+    if coherent and budget > 1000:  # neighbouring rays: the union of 64 walks is not much more than one walk
         assert wave_visits * 8 < lane_visits
