@@ -106,8 +106,10 @@ typedef struct rdh_counters {
                                   that one pipeline's stage tails overlap the others' stage bodies (frames of >= 2 048 blocks) */
 #define RDH_PT_RESTIR_FUSED 1024u /* rdh_restir_direct: round 1's pass 1, one lane per pixel with both walks inside the kernel
                                   (k_restir_pass1), instead of raygen / walk / RIS / walk / resolve (default; same results) */
-#define RDH_PT_WF_SMALL_LISTS 4096u /* wavefront only, for tests: the per-stage lists of literal-class rays hold 4 entries, so that the
-                                  overflow path (such rays stay in the ordinary queues) runs */
+#define RDH_PT_WF_SMALL_LISTS 4096u /* for tests.  Wavefront: the per-stage lists of literal-class rays hold 4 entries, so that the
+                                  overflow path (such rays stay in the ordinary queues) runs.  rdh_gbuffer_render / rdh_restir_direct: a
+                                  wave walks its block as a packet for 4 visits only (256 normally), so that every block goes through
+                                  the hand-over to per-lane walks (traverse.h, packetWalk) */
 #define RDH_PT_PAIRS 32768u    /* per-lane walks over SIBLING PAIRS (one 64-byte record per inner node, shared by the six orderings: a lane
                                   that enters a node fetches both children and tests both boxes in one round trip; the far child is
                                   re-checked when the walk reaches it) instead of the six threaded arrays; same records, same counters.

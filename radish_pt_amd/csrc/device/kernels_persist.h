@@ -908,7 +908,8 @@ __global__ __launch_bounds__(64, PAIRS && !COUNT ? 4 : 1) void k_gbuffer_persist
 // a wave takes one block, walks the union once with one uniform node load per visit, and writes its 64 records.  No lane refill,
 // no persistent grid: a wave's work is one short walk.  Same centre ray, same visits, same record per pixel as k_gbuffer.
 template <bool COUNT, bool DEFER>
-__global__ __launch_bounds__(256) void k_gbuffer_packet(DScene s, DCamera cam, DCamera lastCam, PixelMap pm, GBufPtrs gb, const PersistCounters *pc) {
+__global__ __launch_bounds__(256) void k_gbuffer_packet(DScene s, DCamera cam, DCamera lastCam, PixelMap pm, GBufPtrs gb, const PersistCounters *pc,
+                                                        int budget) {
     const int lane = int(threadIdx.x) & 63;
     const unsigned blk = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (blk >= (unsigned)pm.numBlocks) return;
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(256) void k_gbuffer_packet(DScene s, DCamera cam, D
             }
         }
     }
-    packetWalkAll<COUNT>(s, traced && rs.cls == 0 && end != 0, ord, rs, tmax, hitPrim, hitBary, ws);
+    packetWalkAll<COUNT>(s, traced && rs.cls == 0 && end != 0, ord, rs, tmax, hitPrim, hitBary, ws, budget);
     if (traced) {
         if (hitPrim != -1) nHits++;
         gbufStore(s, cam, lastCam, gb, px.index, rs, hitPrim, hitBary);

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_walk_persistent(DScene s, const float *_
 // Literal-class rays: set aside for k_trace_wg_list when the producer listed them (DEFER), else traced whole by the wave, in place.
 template <bool COUNT, bool DEFER>
 __global__ __launch_bounds__(256) void k_walk_packet(DScene s, const float *__restrict__ rays, long long n, int4 *__restrict__ hits,
-                                                     const int *__restrict__ deferCount, int slotList) {
+                                                     const int *__restrict__ deferCount, int slotList, int budget) {
     const int lane = int(threadIdx.x) & 63;
     const long long i = ((long long)blockIdx.x * 4 + (long long)(threadIdx.x >> 6)) * 64 + lane;
     const int end = s.bvhSize;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_walk_packet(DScene s, const float *__re
             }
         }
     }
-    packetWalkAll<COUNT>(s, traced && rs.cls == 0 && end != 0, ord, rs, tmax, hitPrim, hitBary, ws);
+    packetWalkAll<COUNT>(s, traced && rs.cls == 0 && end != 0, ord, rs, tmax, hitPrim, hitBary, ws, budget);
     if (traced) {
         const bool hit = hitPrim != -1;
         if (hit) nHits++;

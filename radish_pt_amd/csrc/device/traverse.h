@@ -741,12 +741,11 @@ RD_DEV void pairStep(const PairRec *__restrict__ pairs, int2 *stk, int lane, int
 constexpr int kPacketBudget = RD_PACKET_BUDGET;  // visits a wave makes as a packet before its lanes part (see the end of packetWalk)
 template <bool COUNT>
 RD_DEV void packetWalk(const DScene &s, const NodeRec *__restrict__ nd, bool mine, const RaySlab &rs, float &tmax, int &hitPrim, v2 &hitBary,
-                       WalkStats &ws) {
+                       WalkStats &ws, int budget = kPacketBudget) {
     const int end = s.bvhSize;
     const RaySlabPk rp = packSlab(rs);  // the slab test on register pairs (aabbFastPk: the bits of aabbFast)
     int p = mine ? 0 : end;
     int n = __ballot(mine) != 0ull ? 0 : end;
-    int budget = kPacketBudget;
     // (Requesting the two candidates for the next step — n + 1, and the skip target once record n is here — while the lanes test box
     // n was measured: k_gbuffer_packet 389 -> 469 us, k_walk_packet 351 -> 420 us.  Three scalar loads per visit instead of one cost
     // more than the latency they hide: eight waves per SIMD hide it already.)
@@ -818,14 +817,15 @@ RD_DEV void packetWalk(const DScene &s, const NodeRec *__restrict__ nd, bool min
 }
 // The packet walks of a wave whose lanes hold rays of possibly different orderings (a block of primary rays: one, rarely two or three).
 template <bool COUNT>
-RD_DEV void packetWalkAll(const DScene &s, bool mine, int ord, const RaySlab &rs, float &tmax, int &hitPrim, v2 &hitBary, WalkStats &ws) {
+RD_DEV void packetWalkAll(const DScene &s, bool mine, int ord, const RaySlab &rs, float &tmax, int &hitPrim, v2 &hitBary, WalkStats &ws,
+                          int budget = kPacketBudget) {
     unsigned long long todo = __ballot(mine);
     while (todo) {
         const int L = __ffsll((long long)todo) - 1;
         const int q = __builtin_amdgcn_readlane(ord, L);
         const bool now = mine && ord == q;
         todo &= ~__ballot(now);
-        packetWalk<COUNT>(s, s.nodes[0] + (size_t)q * (size_t)(s.bvhSize + 1), now, rs, tmax, hitPrim, hitBary, ws);
+        packetWalk<COUNT>(s, s.nodes[0] + (size_t)q * (size_t)(s.bvhSize + 1), now, rs, tmax, hitPrim, hitBary, ws, budget);
     }
 }
 

@@ -538,7 +538,7 @@ int ensureStackOverflow(rdh_ctx *c, size_t ints) {
 // deferCount / deferList (ReSTIR's lists): literal-class rays have been listed by the producer of `d_rays`; they are traced one
 // per workgroup on the side stream beside the walker, which skips them; the stream waits for both before it goes on.
 int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *d_occ, bool count, const int *deferCount = nullptr,
-               const int *deferList = nullptr, int slotList = 0, bool pairs = false, bool packets = false) {
+               const int *deferList = nullptr, int slotList = 0, bool pairs = false, bool packets = false, int packetBudget = kPacketBudget) {
     const int any = d_occ ? 1 : 0;
     packets = packets && !any && n > 0 && (n + 255) / 256 <= 0x7fffffffll;  // closest hits of a list the caller calls coherent
     // everything that can fail comes BEFORE the fork, so that no error path leaves the side stream un-joined
@@ -586,10 +586,10 @@ int launchWalk(rdh_ctx *c, const float *d_rays, long long n, int4 *d_hits, int *
     } while (0)
     if (packets) {  // one 64-ray chunk per wave, walked as a packet (kernels_walk.h, k_walk_packet)
         const unsigned pgrid = (unsigned)((n + 255) / 256);
-        if (deferCount && count) hipLaunchKernelGGL((k_walk_packet<true, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList);
-        else if (deferCount) hipLaunchKernelGGL((k_walk_packet<false, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList);
-        else if (count) hipLaunchKernelGGL((k_walk_packet<true, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList);
-        else hipLaunchKernelGGL((k_walk_packet<false, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList);
+        if (deferCount && count) hipLaunchKernelGGL((k_walk_packet<true, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList, packetBudget);
+        else if (deferCount) hipLaunchKernelGGL((k_walk_packet<false, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList, packetBudget);
+        else if (count) hipLaunchKernelGGL((k_walk_packet<true, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList, packetBudget);
+        else hipLaunchKernelGGL((k_walk_packet<false, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, d_rays, n, d_hits, deferCount, slotList, packetBudget);
         if (deferCount) {
             hipError_t e1 = hipEventRecord(c->evJoin, c->litStream);
             hipError_t e2 = hipStreamWaitEvent(c->stream, c->evJoin, 0);
@@ -1188,10 +1188,14 @@ int rdh_gbuffer_render(rdh_ctx *c, const rdh_gbuffer *gb, uint32_t flags) {
     }
     if (usePackets(flags)) {  // one 8x8 block per wave, its 64 centre rays walked as a packet (kernels_persist.h, k_gbuffer_packet)
         const unsigned pgrid = ((unsigned)pm.numBlocks + 3u) / 4u;
-        if (count && defer) hipLaunchKernelGGL((k_gbuffer_packet<true, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
-        else if (count) hipLaunchKernelGGL((k_gbuffer_packet<true, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
-        else if (defer) hipLaunchKernelGGL((k_gbuffer_packet<false, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
-        else hipLaunchKernelGGL((k_gbuffer_packet<false, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist);
+        if (count && defer) hipLaunchKernelGGL((k_gbuffer_packet<true, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist,
+                                          (flags & RDH_PT_WF_SMALL_LISTS) ? 4 : kPacketBudget);
+        else if (count) hipLaunchKernelGGL((k_gbuffer_packet<true, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist,
+                                          (flags & RDH_PT_WF_SMALL_LISTS) ? 4 : kPacketBudget);
+        else if (defer) hipLaunchKernelGGL((k_gbuffer_packet<false, true>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist,
+                                          (flags & RDH_PT_WF_SMALL_LISTS) ? 4 : kPacketBudget);
+        else hipLaunchKernelGGL((k_gbuffer_packet<false, false>), dim3(pgrid), dim3(256), 0, c->stream, c->ds, c->cam, last, pm, p, c->dPersist,
+                                          (flags & RDH_PT_WF_SMALL_LISTS) ? 4 : kPacketBudget);
         if (defer) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evJoin, 0));
         return timeEnd(c, "renderGBuffer");
     }
@@ -1337,7 +1341,8 @@ int rdh_restir_direct(rdh_ctx *c, float *d_direct, int iter, int looper, const r
         hipLaunchKernelGGL(k_restir_raygen, dim3(gridBlk), dim3(256), 0, c->stream, c->ds, c->cam, pm, looper, apronBlocks, sp.rays,
                            sp.deferCount, sp.deferList);
         const bool pairs = usePairs(c, flags);
-        if ((rc = launchWalk(c, sp.rays, slots, sp.hits, nullptr, count, defer ? sp.deferCount : nullptr, sp.deferList, 1, pairs, usePackets(flags)))) return rc;
+        if ((rc = launchWalk(c, sp.rays, slots, sp.hits, nullptr, count, defer ? sp.deferCount : nullptr, sp.deferList, 1, pairs, usePackets(flags),
+                             (flags & RDH_PT_WF_SMALL_LISTS) ? 4 : kPacketBudget))) return rc;
         const int nLights = c->ds.lightSamplerLength - (c->ds.envSamplerLength != 0 ? 1 : 0);
         const size_t ldsBytes = (size_t)nLights * sizeof(LightPre) + (size_t)c->ds.lightSamplerLength * sizeof(AliasRec);
         const bool staged = nLights > 0 && ldsBytes <= kRisLdsBytes;

@@ -353,7 +353,8 @@ def test_restir_sequence_bit_exact(gpu_ctx, reuse, faithful):
         gpu_ctx.set_camera(cam)
         gpu_ctx.counters_reset()
         gpu_ctx.restir_direct(img, 0, 40 + f, gb.c_struct(cam), reuse, faithful_ris=faithful,
-                              flags=api.RDH_PT_COUNT | (0 if faithful else api.RDH_PT_NO_PACKETS))
+                              flags=api.RDH_PT_COUNT | (0 if faithful else api.RDH_PT_NO_PACKETS)
+                              | (api.RDH_PT_WF_SMALL_LISTS if (faithful and reuse == 3) else 0))  # one case: packets of 4 visits
         got = img.cpu().numpy()
         assert _frac_outside(got, ref_img) == 0.0
         assert_bit_equal(got, ref_img, f"ReSTIR frame {f} reuse={reuse}")
@@ -368,7 +369,7 @@ def test_restir_sequence_bit_exact(gpu_ctx, reuse, faithful):
     gpu_ctx.restir_free()
 
 
-@pytest.mark.parametrize("kernel", ["packets", "persistent", "one_lane_per_pixel"])
+@pytest.mark.parametrize("kernel", ["packets", "packets_budget_4", "persistent", "one_lane_per_pixel"])
 def test_gbuffer_kernels_bit_exact(gpu_ctx, kernel):
     """renderGBuffer (gBuffer.cu:3-76): the packet kernel (one 8x8 block per wave, its rays walked together: the default), the
     persistent lane-refill kernel and the one-lane-per-pixel kernel all equal the oracle plane by plane, with equal work
@@ -385,7 +386,10 @@ def test_gbuffer_kernels_bit_exact(gpu_ctx, kernel):
     gb_ref = pyoracle.GBufferHost(W, H)
     gb = api.GBuffer()
     gb.create(W, H)
-    flags = api.RDH_PT_COUNT | {"one_lane_per_pixel": api.RDH_PT_MEGA_GBUFFER, "persistent": api.RDH_PT_NO_PACKETS, "packets": 0}[kernel]
+    # packets_budget_4: a wave walks its block as a packet for 4 visits only, then every lane goes on by itself (every block takes the
+    # hand-over of traverse.h's packetWalk; 256 visits normally, which only blocks on silhouettes of large scenes exceed)
+    flags = api.RDH_PT_COUNT | {"one_lane_per_pixel": api.RDH_PT_MEGA_GBUFFER, "persistent": api.RDH_PT_NO_PACKETS, "packets": 0,
+                                "packets_budget_4": api.RDH_PT_WF_SMALL_LISTS}[kernel]
     for cam in cams:
         o.stats_reset() if hasattr(o, "stats_reset") else None
         before = o.stats()
